@@ -1,0 +1,346 @@
+/*
+ * rt_abi.h — C ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * This is the drop-in boundary for the per-pixel render loop of
+ * rookieCookies/raytracing.  The reference has no FFI of its own; the seam
+ * that this ABI replaces is the private method
+ *
+ *     RaytracingCamera::render(&self, world, n_samples, acc_colours, renderer)
+ *                                                   (src/camera.rs:269-306)
+ *
+ * together with everything it reaches (get_ray, ray_colour, Ray::hit_anything,
+ * the leaf hit routines, Material::scatter/emitted, Texture::value,
+ * PerlinNoise).  Scene construction stays on the caller's side: the caller
+ * flattens its Hittable tree / MaterialMap / textures into the plain arrays
+ * below and hands them over once with rt_scene_create.
+ *
+ * Conventions
+ *   - every call returns 0 (RT_OK) or a negative rt_status; rt_last_error()
+ *     returns a thread-local, NUL-terminated description of the last failure;
+ *   - all structs are plain C data, no padding surprises (explicit pads);
+ *   - no exception or panic crosses the boundary;
+ *   - a context is bound to one GPU and is not thread-safe (the reference's
+ *     callers take `&mut Camera`, src/camera.rs:80-122);
+ *   - pointers named d_* are device pointers on the context's GPU, all other
+ *     pointers are host pointers.  Everything passed to rt_scene_create is
+ *     copied; the caller may free it when the call returns.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_NO_DEVICE = -2,
+    RT_ERR_HIP = -3,
+    RT_ERR_OUT_OF_MEMORY = -4,
+    RT_ERR_UNSUPPORTED = -5
+} rt_status;
+
+#define RT_NO_TRANSFORM 0xFFFFFFFFu
+
+/* ---- geometry ----------------------------------------------------------- */
+
+/* Object-to-world placement of a leaf: the composite of the reference's
+ * `Move { RotateY { obj } }` wrappers (src/hittable.rs:47-56,227-243).
+ * A world-space point p maps to object space as
+ *     p' = R * (p - offset),   R: x' = cos*x - sin*z,  z' = sin*x + cos*z
+ * (src/math/ray.rs:207-229).  Any chain of Move/RotateY composes to this. */
+typedef struct rt_transform {
+    float sin_theta;
+    float cos_theta;
+    float offset[3];
+    float _pad[3];
+} rt_transform;
+
+/* Sphere::new(centre, radius, material)          src/hittable.rs:248-259 */
+typedef struct rt_sphere {
+    float centre[3];
+    float radius;
+    uint32_t material;
+    uint32_t prim_id;    /* caller's tag, reported back in rt_hit.prim_id */
+    uint32_t transform;  /* index into transforms or RT_NO_TRANSFORM       */
+    uint32_t _pad;
+} rt_sphere;
+
+/* MovingSphere::new(centre_1, centre_2, radius, material); the centre at ray
+ * time t is centre0 + t*dcentre                  src/hittable.rs:293-310 */
+typedef struct rt_moving_sphere {
+    float centre0[3];
+    float radius;
+    float dcentre[3];
+    uint32_t material;
+    uint32_t prim_id;
+    uint32_t transform;
+    uint32_t _pad[2];
+} rt_moving_sphere;
+
+/* Quad::new(q, u, v, material)                   src/hittable.rs:355-368 */
+typedef struct rt_quad {
+    float q[3];
+    uint32_t material;
+    float u[3];
+    uint32_t prim_id;
+    float v[3];
+    uint32_t transform;
+} rt_quad;
+
+typedef enum rt_prim_kind {
+    RT_PRIM_SPHERE = 0,
+    RT_PRIM_MOVING_SPHERE = 1,
+    RT_PRIM_QUAD = 2,
+    RT_PRIM_MEDIUM = 3
+} rt_prim_kind;
+
+/* Reference to one leaf: (kind, index into the array of that kind). */
+typedef struct rt_prim_ref {
+    uint32_t kind;
+    uint32_t index;
+} rt_prim_ref;
+
+/* ConstantMedium { boundary, neg_inv_density, phase_function }
+ *                                                 src/hittable.rs:412-425
+ * The boundary object is the list of leaves
+ * scene.boundary[first_boundary .. first_boundary + n_boundary).          */
+typedef struct rt_medium {
+    uint32_t first_boundary;
+    uint32_t n_boundary;
+    float neg_inv_density;
+    uint32_t phase_material;  /* the Isotropic material pushed by ::new     */
+    uint32_t prim_id;
+    uint32_t _pad[3];
+} rt_medium;
+
+/* ---- appearance ---------------------------------------------------------- */
+
+typedef enum rt_material_kind {     /* MaterialKind, src/material.rs:14-28 */
+    RT_MAT_LAMBERTIAN = 0,
+    RT_MAT_METAL = 1,               /* param = fuzz_radius                  */
+    RT_MAT_DIELECTRIC = 2,          /* param = refraction_index             */
+    RT_MAT_DIFFUSE_LIGHT = 3,
+    RT_MAT_ISOTROPIC = 4
+} rt_material_kind;
+
+typedef struct rt_material {
+    uint32_t kind;
+    float param;
+    uint32_t texture;
+    uint32_t _pad;
+} rt_material;
+
+typedef enum rt_texture_kind {      /* TextureKind, src/texture.rs:11-36   */
+    RT_TEX_SOLID = 0,               /* colour                               */
+    RT_TEX_CHECKER = 1,             /* scale = inv_scale; even, odd = ids   */
+    RT_TEX_IMAGE = 2,               /* image = id                           */
+    RT_TEX_NOISE = 3                /* perlin = id; scale                   */
+} rt_texture_kind;
+
+typedef struct rt_texture {
+    uint32_t kind;
+    float colour[3];
+    float scale;
+    uint32_t even;
+    uint32_t odd;
+    uint32_t image;
+    uint32_t perlin;
+    uint32_t _pad[3];
+} rt_texture;
+
+typedef enum rt_image_format {
+    RT_IMAGE_RGB8 = 0,    /* 3 bytes per texel; texel value = byte / 255   */
+    RT_IMAGE_RGB32F = 1   /* 3 floats per texel (the reference's Rgb32FImage) */
+} rt_image_format;
+
+/* Row-major, top row first, like image::Rgb32FImage (src/texture.rs:54-64). */
+typedef struct rt_image {
+    uint32_t width;
+    uint32_t height;
+    uint32_t format;
+    uint32_t _pad;
+    const void* texels;
+} rt_image;
+
+/* PerlinNoise tables (src/perlin_noise.rs:8-37). */
+typedef struct rt_perlin {
+    uint32_t point_count;
+    uint32_t _pad;
+    const float* rand_vecs;   /* 3 * point_count                            */
+    const uint32_t* perm_x;   /* point_count each                           */
+    const uint32_t* perm_y;
+    const uint32_t* perm_z;
+} rt_perlin;
+
+typedef struct rt_scene_desc {
+    uint32_t abi_version;     /* RT_ABI_VERSION */
+    uint32_t n_spheres;
+    uint32_t n_moving_spheres;
+    uint32_t n_quads;
+    uint32_t n_media;
+    uint32_t n_world;         /* leaves of World::entry (src/lib.rs:17-26)  */
+    uint32_t n_boundary;      /* leaves that only bound media               */
+    uint32_t n_transforms;
+    uint32_t n_materials;
+    uint32_t n_textures;
+    uint32_t n_images;
+    uint32_t n_perlins;
+    const rt_sphere* spheres;
+    const rt_moving_sphere* moving_spheres;
+    const rt_quad* quads;
+    const rt_medium* media;
+    const rt_prim_ref* world;
+    const rt_prim_ref* boundary;
+    const rt_transform* transforms;
+    const rt_material* materials;   /* index = MaterialId (src/material.rs:31-49) */
+    const rt_texture* textures;
+    const rt_image* images;
+    const rt_perlin* perlins;
+} rt_scene_desc;
+
+/* The fields of RaytracingCamera (src/camera.rs:206-218) as computed by
+ * RaytracingCamera::new (src/camera.rs:222-266). */
+typedef struct rt_camera_desc {
+    uint32_t width;
+    uint32_t height;
+    uint32_t max_depth;
+    float defocus_angle;
+    float centre[3];
+    float pixel00_loc[3];
+    float pixel_delta_u[3];
+    float pixel_delta_v[3];
+    float defocus_disk_u[3];
+    float defocus_disk_v[3];
+    float background_colour[3];
+    float _pad;
+} rt_camera_desc;
+
+/* ---- per-ray interface (parity checks) ------------------------------------ */
+
+/* Ray { origin, direction, time } (src/math/ray.rs:8-13); the interval is the
+ * one Ray::hit_anything starts from, normally (0.001, +inf) (:64-65).       */
+typedef struct rt_ray {
+    float origin[3];
+    float time;
+    float direction[3];
+    float tmin;
+    float tmax;
+    uint32_t rng_pixel;    /* key of the medium draw (see rt_render_*)       */
+    uint32_t rng_sample;
+    uint32_t rng_bounce;
+} rt_ray;
+
+/* HitRecord (src/hittable.rs:7-16) plus the leaf tag. hit == 0 means miss and
+ * leaves the other fields zero. */
+typedef struct rt_hit {
+    float t;
+    float point[3];
+    float normal[3];
+    float u;
+    float v;
+    uint32_t prim_id;
+    uint32_t material;
+    uint32_t front_face;
+    uint32_t hit;
+    uint32_t _pad[3];
+} rt_hit;
+
+typedef struct rt_counters {
+    uint64_t samples;        /* camera paths started                          */
+    uint64_t segments;       /* rays cast (calls of Ray::hit_anything)        */
+    uint64_t node_visits;    /* BVH nodes popped                              */
+    uint64_t sphere_tests;
+    uint64_t quad_tests;
+    uint64_t medium_tests;
+    uint64_t hits;           /* segments that hit something                   */
+    uint64_t _pad;
+} rt_counters;
+
+typedef enum rt_finalize_mode {
+    RT_FINALIZE_MEAN = 0,     /* acc / n            -> 4 floats per pixel     */
+    RT_FINALIZE_SQRT = 1,     /* Camera::hdr_render, src/camera.rs:107-122    */
+    RT_FINALIZE_TONEMAP_RGBA = 2 /* Camera::realtime_render, :89-104 -> u32  */
+} rt_finalize_mode;
+
+typedef struct rt_ctx rt_ctx;
+typedef struct rt_scene rt_scene;
+
+const char* rt_last_error(void);
+uint32_t rt_abi_version(void);
+
+/* One context per GPU.  device_id is the HIP device ordinal. */
+int rt_ctx_create(int device_id, rt_ctx** out);
+int rt_ctx_destroy(rt_ctx* ctx);
+/* Stream (hipStream_t) on which all work of this context is enqueued;
+ * NULL selects the default stream. */
+int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream);
+/* Paths kept in flight per batch (queue capacity); 0 restores the default. */
+int rt_ctx_set_batch_paths(rt_ctx* ctx, uint64_t max_paths);
+/* Turn the work counters on or off (off by default: they cost atomics). */
+int rt_ctx_set_counters(rt_ctx* ctx, int enabled);
+int rt_ctx_get_counters(rt_ctx* ctx, rt_counters* out, int reset);
+
+/* Replaces World::new + the walk a Rust caller would do over its Hittable
+ * tree (src/lib.rs:17-26, src/hittable.rs:35-57): copies the description,
+ * bakes transforms, builds the flattened BVH and uploads everything. */
+int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out);
+int rt_scene_destroy(rt_scene* scene);
+
+/* Replaces `n_samples` consecutive calls of RaytracingCamera::render
+ * (src/camera.rs:269-306) with sample numbers first_sample,
+ * first_sample+1, ... (the reference counts from 1, src/camera.rs:82-83):
+ * for every pixel, acc[pixel] += sum over those samples of the path radiance.
+ * acc is width*height*4 floats, row-major, row 0 on top, lane 3 untouched
+ * (the reference's Vec<f32x4> acc_colours, src/camera.rs:25).  Random numbers
+ * are a pure function of (seed, pixel, sample, bounce), so the result does not
+ * depend on batch size, scheduling or how samples are split over GPUs.
+ * Blocking; acc_host is read and written on the host. */
+int rt_render_accumulate(rt_scene* scene, const rt_camera_desc* cam,
+                         uint64_t seed, uint32_t first_sample,
+                         uint32_t n_samples, float* acc_host);
+/* Same with the accumulation buffer resident on the GPU; enqueues on the
+ * context's stream and returns without waiting. */
+int rt_render_accumulate_device(rt_scene* scene, const rt_camera_desc* cam,
+                                uint64_t seed, uint32_t first_sample,
+                                uint32_t n_samples, float* d_acc);
+
+/* Replaces the per-pixel closures of Camera::hdr_render / realtime_render
+ * (src/camera.rs:95-100,115-118) and Colour::to_rgba (src/math/vec3.rs:252-259).
+ * d_acc: n_pixels*4 floats.  d_out: n_pixels*4 floats (modes 0, 1) or
+ * n_pixels uint32 (mode 2).  Enqueues on the context's stream. */
+int rt_finalize_device(rt_ctx* ctx, const float* d_acc, uint64_t n_pixels,
+                       uint32_t total_samples, int mode, float exposure,
+                       void* d_out);
+/* Host-buffer convenience wrapper of rt_finalize_device (blocking). */
+int rt_finalize(rt_ctx* ctx, const float* acc_host, uint64_t n_pixels,
+                uint32_t total_samples, int mode, float exposure,
+                void* out_host);
+
+/* Replaces Ray::hit_anything (src/math/ray.rs:59-275) on a batch of rays:
+ * closest hit over World::entry including constant media.  Host buffers,
+ * blocking.  seed keys the medium free-path draw as in rt_render_*. */
+int rt_intersect_batch(rt_scene* scene, const rt_ray* rays, size_t n,
+                       uint64_t seed, rt_hit* out);
+
+/* Block until all work enqueued by this context has finished. */
+int rt_ctx_synchronize(rt_ctx* ctx);
+
+/* Timing of the most recent rt_render_accumulate*_ call measured with HIP
+ * events on the context's stream: total and per-phase milliseconds, launches
+ * per phase.  Valid after rt_ctx_synchronize.  phase: 0 raygen, 1 extend,
+ * 2 shade, 3 accumulate. */
+int rt_ctx_last_render_ms(rt_ctx* ctx, float* total_ms);
+int rt_ctx_set_phase_timing(rt_ctx* ctx, int enabled);
+int rt_ctx_phase_ms(rt_ctx* ctx, int phase, float* ms, uint32_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

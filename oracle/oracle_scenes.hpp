@@ -1,0 +1,374 @@
+// oracle_scenes.hpp — the reference's scene builders (src/main.rs:291-731),
+// restated on the oracle's Scene type.  TEST INFRASTRUCTURE ONLY (see
+// oracle_core.hpp).  Draw order of the xoshiro stream is the reference's, so
+// every sphere centre, box height, perlin table and material is bit-identical
+// to what the Rust binary would build.
+//
+// Scene ids 0..8 are the reference's `--scene` numbers.  Ids >= 100 are the
+// benchmark configurations that have no single builder in the reference:
+//   100  earth + perlin spheres under a ceiling light (texture/noise path)
+//   101  Cornell box with box2 replaced by a glass sphere (dielectric path)
+//   102  N random lambertian spheres (BVH stress)
+#pragma once
+#include "oracle_core.hpp"
+
+namespace orc {
+
+struct BuildOptions {
+    size_t width = 0, height = 0;   // 0 = the reference's default at resolution_scale 100
+    size_t max_depth = 25;          // src/main.rs:32
+    const Image* earth = nullptr;   // decoded earthmap.jpg (needed by scenes 4, 8, 100)
+    uint64_t stress_count = 100000; // scene 102
+};
+
+inline void pick_resolution(const BuildOptions& o, size_t dw, size_t dh, size_t& w, size_t& h) {
+    w = o.width ? o.width : dw;
+    h = o.height ? o.height : dh;
+}
+
+// src/main.rs:553-612
+inline void original_bouncing_spheres(Scene& s, const BuildOptions& o) {
+    std::vector<Hittable> world;
+    uint32_t material_ground = s.push_material(
+        Material::LAMBERTIAN, s.tex_checker(0.64f, s.tex_colour(Vec3(0, 0, 0)), s.tex_colour(Vec3(1, 1, 1))));
+    world.push_back(s.sphere(Vec3(0.0f, -1000.0f, 0.0f), 1000.0f, material_ground));
+    Seed seed{{69, 420, 420, 69}};
+    for (int a = -11; a < 11; ++a) {
+        for (int b = -11; b < 11; ++b) {
+            float choose_mat = seed.next_f32();
+            float cx = (float)a + 9.0f * seed.next_f32();
+            float cz = (float)b + 9.0f * seed.next_f32();
+            Vec3 centre(cx, 0.2f, cz);
+            Vec3 centre_2 = centre + Vec3(0.0f, seed.next_f32() * 0.2f, 0.0f);
+            if (length(centre - Vec3(4.0f, 0.2f, 0.0f)) <= 0.9f) continue;
+            uint32_t mat;
+            if (choose_mat < 0.8f) {
+                Vec3 c1(seed.next_f32(), 0, 0); c1.y = seed.next_f32(); c1.z = seed.next_f32();
+                Vec3 c2(seed.next_f32(), 0, 0); c2.y = seed.next_f32(); c2.z = seed.next_f32();
+                mat = s.push_material(Material::LAMBERTIAN, s.tex_colour(c1 * c2));
+            } else if (choose_mat < 0.95f) {
+                Vec3 albedo; albedo.x = seed.next_f32_range(0.5f, 1.0f); albedo.y = seed.next_f32_range(0.5f, 1.0f);
+                albedo.z = seed.next_f32_range(0.5f, 1.0f);
+                float fuzz = seed.next_f32_range(0.0f, 0.5f);
+                mat = s.push_material(Material::METAL, s.tex_colour(albedo), fuzz);
+            } else {
+                mat = s.push_material(Material::DIELECTRIC, s.tex_colour(Vec3(1, 1, 1)), 1.5f);
+            }
+            world.push_back(s.moving_sphere(centre, centre_2, 0.2f, mat));
+        }
+    }
+    uint32_t m1 = s.push_material(Material::DIELECTRIC, s.tex_colour(Vec3(1.0f, 1.0f, 1.0f)), 1.5f);
+    world.push_back(s.sphere(Vec3(0.0f, 1.0f, 0.0f), 1.0f, m1));
+    uint32_t m2 = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(0.4f, 0.2f, 0.1f)));
+    world.push_back(s.sphere(Vec3(-4.0f, 1.0f, 0.0f), 1.0f, m2));
+    uint32_t m3 = s.push_material(Material::METAL, s.tex_colour(Vec3(0.7f, 0.6f, 0.5f)), 0.0f);
+    world.push_back(s.sphere(Vec3(4.0f, 1.0f, 0.0f), 1.0f, m3));
+    s.entry = s.alloc(s.bvh(world));
+    size_t w, h; pick_resolution(o, 1600, 900, w, h);
+    s.camera_new(Vec3(-10.0f, 5.0f, -10.0f), w, h, o.max_depth, 20.0f, Vec3(0.0f, 2.0f, 0.0f), 0.0f, 10.0f, Vec3(0.7f, 0.7f, 0.7f));
+    s.change_pitch_yaw_by(-15.0f, 45.0f);
+}
+
+// src/main.rs:615-684
+inline void bouncing_spheres_night(Scene& s, const BuildOptions& o) {
+    std::vector<Hittable> world;
+    uint32_t material_ground = s.push_material(
+        Material::LAMBERTIAN, s.tex_checker(0.64f, s.tex_colour(Vec3(0, 0, 0)), s.tex_colour(Vec3(1, 1, 1))));
+    world.push_back(s.sphere(Vec3(0.0f, -1000.0f, 0.0f), 1000.0f, material_ground));
+    Seed seed{{69, 420, 420, 69}};
+    auto rand3 = [&]() { Vec3 c; c.x = seed.next_f32(); c.y = seed.next_f32(); c.z = seed.next_f32(); return c; };
+    for (int a = -11; a < 11; ++a) {
+        for (int b = -11; b < 11; ++b) {
+            float choose_mat = seed.next_f32();
+            float cx = (float)a + 9.0f * seed.next_f32();
+            float cz = (float)b + 9.0f * seed.next_f32();
+            Vec3 centre(cx, 0.2f, cz);
+            Vec3 centre_2 = centre + Vec3(0.0f, seed.next_f32() * 0.2f, 0.0f);
+            if (length(centre - Vec3(4.0f, 0.2f, 0.0f)) <= 0.9f) continue;
+            uint32_t mat;
+            if (choose_mat < 0.5f) {
+                Vec3 c1 = rand3(); Vec3 c2 = rand3();
+                mat = s.push_material(Material::LAMBERTIAN, s.tex_colour(c1 * c2));
+            } else if (choose_mat < 0.8f) {
+                Vec3 c1 = rand3(); Vec3 c2 = rand3();
+                mat = s.push_material(Material::DIFFUSE_LIGHT, s.tex_colour(25.0f * (c1 * c2)));
+            } else if (choose_mat < 0.95f) {
+                Vec3 albedo; albedo.x = seed.next_f32_range(0.5f, 1.0f); albedo.y = seed.next_f32_range(0.5f, 1.0f);
+                albedo.z = seed.next_f32_range(0.5f, 1.0f);
+                float fuzz = seed.next_f32_range(0.0f, 0.5f);
+                mat = s.push_material(Material::METAL, s.tex_colour(albedo), fuzz);
+            } else {
+                mat = s.push_material(Material::DIELECTRIC, s.tex_colour(Vec3(1, 1, 1)), 1.5f);
+            }
+            Hittable hittable = s.moving_sphere(centre, centre_2, 0.2f, mat);
+            if (seed.next_f32() < 0.125f) {
+                s.perlins.push_back(PerlinNoise::make(seed, 64));
+                const PerlinNoise* noise = &s.perlins.back();
+                const Texture* texture = s.tex_noise(noise, seed.next_f32() * 2.0f);
+                const Hittable* boundary = s.alloc(hittable);
+                // argument order of ConstantMedium::new(&mut mmap, boundary, seed.next_f32(), texture): the
+                // texture (and its scale draw) is built before the call, the density draw is an argument
+                float density = seed.next_f32();
+                hittable = s.constant_medium(boundary, density, texture);
+            }
+            world.push_back(hittable);
+        }
+    }
+    uint32_t m1 = s.push_material(Material::DIELECTRIC, s.tex_colour(Vec3(1.0f, 1.0f, 1.0f)), 1.5f);
+    world.push_back(s.sphere(Vec3(0.0f, 1.0f, 0.0f), 1.0f, m1));
+    uint32_t m2 = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(0.4f, 0.2f, 0.1f)));
+    world.push_back(s.sphere(Vec3(-4.0f, 1.0f, 0.0f), 1.0f, m2));
+    uint32_t m3 = s.push_material(Material::METAL, s.tex_colour(Vec3(0.7f, 0.6f, 0.5f)), 0.0f);
+    world.push_back(s.move_by(s.sphere(Vec3(4.0f, 1.0f, 0.0f), 1.0f, m3), Vec3(1.0f, 1.0f, 1.0f)));
+    s.entry = s.alloc(s.bvh(world));
+    size_t w, h; pick_resolution(o, 1600, 900, w, h);
+    s.camera_new(Vec3(-10.0f, 5.0f, -10.0f), w, h, o.max_depth, 20.0f, Vec3(0.0f, 2.0f, 0.0f), 0.0f, 10.0f, Vec3(0.0f, 0.0f, 0.0f));
+    s.change_pitch_yaw_by(-15.0f, 45.0f);
+}
+
+// src/main.rs:523-550
+inline void quads(Scene& s, const BuildOptions& o) {
+    std::vector<Hittable> world;
+    uint32_t left_red = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(1.0f, 0.2f, 0.2f)));
+    uint32_t back_green = s.push_material(Material::DIFFUSE_LIGHT, s.tex_colour(10.0f * Vec3(0.2f, 1.0f, 0.2f)));
+    uint32_t right_blue = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(0.2f, 0.2f, 1.0f)));
+    uint32_t upper_orange = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(1.0f, 0.5f, 0.0f)));
+    uint32_t lower_teal = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(0.2f, 0.8f, 0.8f)));
+    world.push_back(s.quad(Vec3(-3.0f, -2.0f, 5.0f), Vec3(0.0f, 0.0f, -4.0f), Vec3(0.0f, 4.0f, 0.0f), left_red));
+    world.push_back(s.quad(Vec3(-2.0f, -2.0f, 0.0f), Vec3(4.0f, 0.0f, 0.0f), Vec3(0.0f, 4.0f, 0.0f), back_green));
+    world.push_back(s.quad(Vec3(3.0f, -2.0f, 1.0f), Vec3(0.0f, 0.0f, 4.0f), Vec3(0.0f, 4.0f, 0.0f), right_blue));
+    world.push_back(s.quad(Vec3(-2.0f, 3.0f, 1.0f), Vec3(4.0f, 0.0f, 0.0f), Vec3(0.0f, 0.0f, 4.0f), upper_orange));
+    world.push_back(s.quad(Vec3(-2.0f, -3.0f, 5.0f), Vec3(4.0f, 0.0f, 0.0f), Vec3(0.0f, 0.0f, -4.0f), lower_teal));
+    size_t w, h; pick_resolution(o, 1000, 1000, w, h);
+    s.camera_new(Vec3(0.0f, 0.0f, 9.0f), w, h, o.max_depth, 80.0f, Vec3(0.0f, 2.0f, 0.0f), 0.0f, 10.0f, Vec3(0, 0, 0));
+    s.change_pitch_yaw_by(0.0f, -90.0f);
+    s.entry = s.alloc(s.bvh(world));
+}
+
+// src/main.rs:499-520
+inline void simple_light(Scene& s, const BuildOptions& o) {
+    std::vector<Hittable> world;
+    Seed pseed{{1, 2, 3, 4}};
+    s.perlins.push_back(PerlinNoise::make(pseed, 100));
+    const Texture* pertext = s.tex_noise(&s.perlins.back(), 4.0f);
+    world.push_back(s.sphere(Vec3(0.0f, -1000.0f, 0.0f), 1000.0f, s.push_material(Material::LAMBERTIAN, pertext)));
+    world.push_back(s.sphere(Vec3(0.0f, 2.0f, 0.0f), 2.0f, s.push_material(Material::LAMBERTIAN, pertext)));
+    uint32_t diff_light = s.push_material(Material::DIFFUSE_LIGHT, s.tex_colour(Vec3(4.0f, 4.0f, 4.0f)));
+    world.push_back(s.quad(Vec3(3.0f, 1.0f, -2.0f), Vec3(2.0f, 0.0f, 0.0f), Vec3(0.0f, 2.0f, 0.0f), diff_light));
+    size_t w, h; pick_resolution(o, 1600, 900, w, h);
+    s.camera_new(Vec3(26.0f, 2.0f, 6.0f), w, h, o.max_depth, 20.0f, Vec3(0.0f, 2.0f, 0.0f), 0.0f, 10.0f, Vec3(0, 0, 0));
+    s.change_pitch_yaw_by(0.0f, 200.0f);
+    s.entry = s.alloc(s.bvh(world));
+}
+
+// src/main.rs:687-712.  The reference opens "earthmap3.png", which it does not
+// ship; the earth map it does ship (earthmap.jpg) stands in.
+inline void world_sphere(Scene& s, const BuildOptions& o) {
+    std::vector<Hittable> world;
+    uint32_t material_ground = s.push_material(Material::DIFFUSE_LIGHT, s.tex_image(o.earth));
+    world.push_back(s.sphere(Vec3(0.0f, 0.0f, 0.0f), 2.0f, material_ground));
+    uint32_t checker = s.push_material(
+        Material::LAMBERTIAN, s.tex_checker(1.0f, s.tex_colour(Vec3(0, 0, 0)), s.tex_colour(Vec3(1, 1, 1))));
+    world.push_back(s.sphere(Vec3(0.0f, -1002.0f, 0.0f), 1000.0f, checker));
+    s.entry = s.alloc(s.bvh(world));
+    size_t w, h; pick_resolution(o, 1600, 1000, w, h);
+    s.camera_new(Vec3(-10.0f, 5.0f, -10.0f), w, h, o.max_depth, 20.0f, Vec3(0.0f, 2.0f, 0.0f), 0.0f, 10.0f,
+                 Vec3(0.98431373f, 0.56470588f, 0.38431373f));
+    s.change_pitch_yaw_by(-20.0f, 40.0f);
+}
+
+// src/main.rs:715-731
+inline void checkered_spheres(Scene& s, const BuildOptions& o) {
+    std::vector<Hittable> world;
+    uint32_t checker = s.push_material(
+        Material::LAMBERTIAN, s.tex_checker(1.0f, s.tex_colour(Vec3(0, 0, 0)), s.tex_colour(Vec3(1, 1, 1))));
+    world.push_back(s.sphere(Vec3(0.0f, -10.0f, 0.0f), 10.0f, checker));
+    world.push_back(s.sphere(Vec3(0.0f, 10.0f, 0.0f), 10.0f, checker));
+    s.entry = s.alloc(s.bvh(world));
+    size_t w, h; pick_resolution(o, 1600, 1000, w, h);
+    s.camera_new(Vec3(-25.0f, 0.0f, 0.0f), w, h, o.max_depth, 20.0f, Vec3(0.0f, 2.0f, 0.0f), 0.0f, 10.0f, Vec3(0.7f, 0.7f, 0.7f));
+}
+
+inline void cornell_walls(Scene& s, std::vector<Hittable>& world, uint32_t& white) {
+    uint32_t red = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(0.65f, 0.05f, 0.05f)));
+    white = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(0.73f, 0.73f, 0.73f)));
+    uint32_t green = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(0.12f, 0.45f, 0.15f)));
+    uint32_t light = s.push_material(Material::DIFFUSE_LIGHT, s.tex_colour(Vec3(15.0f, 15.0f, 15.0f)));
+    world.push_back(s.quad(Vec3(555.0f, 0.0f, 0.0f), Vec3(0.0f, 555.0f, 0.0f), Vec3(0.0f, 0.0f, 555.0f), green));
+    world.push_back(s.quad(Vec3(0.0f, 0.0f, 0.0f), Vec3(0.0f, 555.0f, 0.0f), Vec3(0.0f, 0.0f, 555.0f), red));
+    world.push_back(s.quad(Vec3(343.0f, 554.0f, 332.0f), Vec3(-130.0f, 0.0f, 0.0f), Vec3(0.0f, 0.0f, -105.0f), light));
+    world.push_back(s.quad(Vec3(0.0f, 0.0f, 0.0f), Vec3(555.0f, 0.0f, 0.0f), Vec3(0.0f, 0.0f, 555.0f), white));
+    world.push_back(s.quad(Vec3(555.0f, 555.0f, 555.0f), Vec3(-555.0f, 0.0f, 0.0f), Vec3(0.0f, 0.0f, -555.0f), white));
+    world.push_back(s.quad(Vec3(0.0f, 0.0f, 555.0f), Vec3(555.0f, 0.0f, 0.0f), Vec3(0.0f, 555.0f, 0.0f), white));
+}
+
+inline void cornell_camera(Scene& s, const BuildOptions& o) {
+    size_t w, h; pick_resolution(o, 1000, 1000, w, h);
+    s.camera_new(Vec3(278.0f, 278.0f, -800.0f), w, h, o.max_depth, 40.0f, Vec3(0.0f, 2.0f, 0.0f), 0.0f, 10.0f, Vec3(0, 0, 0));
+    s.change_pitch_yaw_by(0.0f, 90.0f);
+}
+
+// src/main.rs:413-448; variant 101 swaps box2 for a glass sphere
+inline void cornell_box(Scene& s, const BuildOptions& o, bool glass_sphere) {
+    std::vector<Hittable> world;
+    uint32_t white;
+    cornell_walls(s, world, white);
+    Hittable box1 = s.move_by(s.rotate_y_by(s.box_of_quads(Vec3(0, 0, 0), Vec3(165.0f, 330.0f, 165.0f), white), 15.0f),
+                              Vec3(265.0f, 0.0f, 295.0f));
+    world.push_back(box1);
+    if (!glass_sphere) {
+        Hittable box2 = s.move_by(s.rotate_y_by(s.box_of_quads(Vec3(0, 0, 0), Vec3(165.0f, 165.0f, 165.0f), white), -18.0f),
+                                  Vec3(130.0f, 0.0f, 65.0f));
+        world.push_back(box2);
+    } else {
+        uint32_t glass = s.push_material(Material::DIELECTRIC, s.tex_colour(Vec3(1, 1, 1)), 1.5f);
+        world.push_back(s.sphere(Vec3(190.0f, 90.0f, 190.0f), 90.0f, glass));
+    }
+    cornell_camera(s, o);
+    s.entry = s.alloc(s.bvh(world));
+}
+
+// src/main.rs:451-496
+inline void cornell_box_fog(Scene& s, const BuildOptions& o) {
+    std::vector<Hittable> world;
+    uint32_t white;
+    cornell_walls(s, world, white);
+    Hittable box1 = s.move_by(s.rotate_y_by(s.box_of_quads(Vec3(0, 0, 0), Vec3(165.0f, 330.0f, 165.0f), white), 15.0f),
+                              Vec3(265.0f, 0.0f, 295.0f));
+    Hittable fog1 = s.constant_medium(s.alloc(box1), 0.01f, s.tex_colour(Vec3(0, 0, 0)));
+    Hittable box2 = s.move_by(s.rotate_y_by(s.box_of_quads(Vec3(0, 0, 0), Vec3(165.0f, 165.0f, 165.0f), white), -18.0f),
+                              Vec3(130.0f, 0.0f, 65.0f));
+    Hittable fog2 = s.constant_medium(s.alloc(box2), 0.01f, s.tex_colour(Vec3(1, 1, 1)));
+    world.push_back(fog1);
+    world.push_back(fog2);
+    cornell_camera(s, o);
+    s.entry = s.alloc(s.bvh(world));
+}
+
+// src/main.rs:291-410
+inline void the_final_scene(Scene& s, const BuildOptions& o) {
+    Seed seed{{69, 420, 420, 69}};
+    std::vector<Hittable> world;
+    std::vector<Hittable> boxes_ground;
+    uint32_t ground = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(0.48f, 0.83f, 0.53f)));
+    const int boxes_per_side = 20;
+    for (int ii = 0; ii < boxes_per_side; ++ii) {
+        float i = (float)ii;
+        for (int jj = 0; jj < boxes_per_side; ++jj) {
+            float j = (float)jj;
+            float w = 100.0f;
+            float x0 = -1000.0f + i * w;
+            float z0 = -1000.0f + j * w;
+            float y0 = 0.0f;
+            float x1 = x0 + w;
+            float y1 = seed.next_f32_range(1.0f, 101.0f);
+            float z1 = z0 + w;
+            boxes_ground.push_back(s.box_of_quads(Vec3(x0, y0, z0), Vec3(x1, y1, z1), ground));
+        }
+    }
+    world.push_back(s.bvh(boxes_ground));
+
+    uint32_t light = s.push_material(Material::DIFFUSE_LIGHT, s.tex_colour(Vec3(7.0f, 7.0f, 7.0f)));
+    world.push_back(s.quad(Vec3(123.0f, 553.0f, 147.0f), Vec3(300.0f, 0.0f, 0.0f), Vec3(0.0f, 0.0f, 265.0f), light));
+
+    Vec3 centre1(400.0f, 400.0f, 200.0f);
+    Vec3 centre2 = centre1 + Vec3(30.0f, 0.0f, 0.0f);
+    uint32_t sphere_material = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(0.7f, 0.3f, 0.1f)));
+    world.push_back(s.moving_sphere(centre1, centre2, 50.0f, sphere_material));
+
+    world.push_back(s.sphere(Vec3(260.0f, 150.0f, 45.0f), 50.0f,
+                             s.push_material(Material::DIELECTRIC, s.tex_colour(Vec3(1, 1, 1)), 1.5f)));
+    world.push_back(s.sphere(Vec3(0.0f, 150.0f, 145.0f), 50.0f,
+                             s.push_material(Material::METAL, s.tex_colour(Vec3(0.8f, 0.8f, 0.9f)), 1.0f)));
+
+    Hittable boundary = s.sphere(Vec3(360.0f, 150.0f, 145.0f), 70.0f,
+                                 s.push_material(Material::DIELECTRIC, s.tex_colour(Vec3(1, 1, 1)), 1.5f));
+    world.push_back(boundary);
+    world.push_back(s.constant_medium(s.alloc(boundary), 0.2f, s.tex_colour(Vec3(0.2f, 0.4f, 0.9f))));
+
+    Hittable boundary2 = s.sphere(Vec3(0.0f, 0.0f, 0.0f), 5000.0f,
+                                  s.push_material(Material::DIELECTRIC, s.tex_colour(Vec3(1, 1, 1)), 1.5f));
+    world.push_back(boundary2);
+    world.push_back(s.constant_medium(s.alloc(boundary2), 0.00005f, s.tex_colour(Vec3(1, 1, 1))));
+
+    uint32_t earth_material = s.push_material(Material::LAMBERTIAN, s.tex_image(o.earth));
+    world.push_back(s.sphere(Vec3(400.0f, 200.0f, 400.0f), 100.0f, earth_material));
+
+    s.perlins.push_back(PerlinNoise::make(seed, 256));
+    uint32_t pertext = s.push_material(Material::LAMBERTIAN, s.tex_noise(&s.perlins.back(), 0.2f));
+    world.push_back(s.sphere(Vec3(220.0f, 280.0f, 300.0f), 80.0f, pertext));
+
+    std::vector<Hittable> stress_balls;
+    uint32_t white = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(1, 1, 1)));
+    const int ns = 1000;
+    for (int i = 0; i < ns; ++i) {
+        Vec3 c; c.x = seed.next_f32_range(0.0f, 165.0f); c.y = seed.next_f32_range(0.0f, 165.0f); c.z = seed.next_f32_range(0.0f, 165.0f);
+        stress_balls.push_back(s.sphere(c, 10.0f, white));
+    }
+    world.push_back(s.move_by(s.rotate_y_by(s.bvh(stress_balls), 15.0f), Vec3(-100.0f, 270.0f, 395.0f)));
+
+    size_t w, h; pick_resolution(o, 1000, 1000, w, h);
+    s.camera_new(Vec3(478.0f, 278.0f, -600.0f), w, h, o.max_depth, 40.0f, Vec3(0.0f, 1.0f, 0.0f), 0.0f, 10.0f, Vec3(0, 0, 0));
+    s.entry = s.alloc(s.bvh(world));
+    s.change_pitch_yaw_by(0.0f, 108.0f);
+}
+
+// Benchmark configuration "earth image-textured sphere + perlin-noise spheres":
+// the reference has no single such scene (its scene 4 needs a missing asset),
+// so this composite reuses scene 3's perlin setup (src/main.rs:503-505) and
+// scene 8's earth material (src/main.rs:369-370) under a ceiling light.
+inline void earth_and_perlin(Scene& s, const BuildOptions& o) {
+    std::vector<Hittable> world;
+    Seed pseed{{1, 2, 3, 4}};
+    s.perlins.push_back(PerlinNoise::make(pseed, 100));
+    const Texture* pertext = s.tex_noise(&s.perlins.back(), 4.0f);
+    world.push_back(s.sphere(Vec3(0.0f, -1000.0f, 0.0f), 1000.0f, s.push_material(Material::LAMBERTIAN, pertext)));
+    world.push_back(s.sphere(Vec3(0.0f, 2.0f, 0.0f), 2.0f, s.push_material(Material::LAMBERTIAN, pertext)));
+    world.push_back(s.sphere(Vec3(0.0f, 2.0f, 4.5f), 2.0f, s.push_material(Material::LAMBERTIAN, pertext)));
+    uint32_t earth_material = s.push_material(Material::LAMBERTIAN, s.tex_image(o.earth));
+    world.push_back(s.sphere(Vec3(0.0f, 2.0f, -4.5f), 2.0f, earth_material));
+    uint32_t diff_light = s.push_material(Material::DIFFUSE_LIGHT, s.tex_colour(Vec3(4.0f, 4.0f, 4.0f)));
+    world.push_back(s.quad(Vec3(-2.0f, 7.0f, -3.0f), Vec3(4.0f, 0.0f, 0.0f), Vec3(0.0f, 0.0f, 6.0f), diff_light));
+    size_t w, h; pick_resolution(o, 1920, 1080, w, h);
+    s.camera_new(Vec3(26.0f, 3.0f, 6.0f), w, h, o.max_depth, 20.0f, Vec3(0.0f, 2.0f, 0.0f), 0.0f, 10.0f, Vec3(0, 0, 0));
+    s.change_pitch_yaw_by(-2.0f, 193.0f);
+    s.entry = s.alloc(s.bvh(world));
+}
+
+// Benchmark configuration "synthetic BVH stress": N lambertian spheres, centres
+// U[0,1000)^3, radii U[0.05,0.5) from Seed([N,1,2,3]) (x, y, z, radius per sphere).
+inline void bvh_stress(Scene& s, const BuildOptions& o) {
+    std::vector<Hittable> world;
+    uint32_t grey = s.push_material(Material::LAMBERTIAN, s.tex_colour(Vec3(0.5f, 0.5f, 0.5f)));
+    Seed seed{{o.stress_count, 1, 2, 3}};
+    world.reserve(o.stress_count);
+    for (uint64_t i = 0; i < o.stress_count; ++i) {
+        Vec3 c; c.x = seed.next_f32_range(0.0f, 1000.0f); c.y = seed.next_f32_range(0.0f, 1000.0f); c.z = seed.next_f32_range(0.0f, 1000.0f);
+        float r = seed.next_f32_range(0.05f, 0.5f);
+        world.push_back(s.sphere(c, r, grey));
+    }
+    s.entry = s.alloc(s.bvh(world));
+    size_t w, h; pick_resolution(o, 1920, 1080, w, h);
+    s.camera_new(Vec3(-800.0f, 500.0f, -800.0f), w, h, o.max_depth, 40.0f, Vec3(0.0f, 1.0f, 0.0f), 0.0f, 10.0f, Vec3(1, 1, 1));
+    s.change_pitch_yaw_by(0.0f, 45.0f);
+}
+
+inline bool build_builtin(Scene& s, int id, const BuildOptions& o) {
+    switch (id) {
+        case 0: original_bouncing_spheres(s, o); return true;
+        case 1: bouncing_spheres_night(s, o); return true;
+        case 2: quads(s, o); return true;
+        case 3: simple_light(s, o); return true;
+        case 4: if (!o.earth) return false; world_sphere(s, o); return true;
+        case 5: checkered_spheres(s, o); return true;
+        case 6: cornell_box(s, o, false); return true;
+        case 7: cornell_box_fog(s, o); return true;
+        case 8: if (!o.earth) return false; the_final_scene(s, o); return true;
+        case 100: if (!o.earth) return false; earth_and_perlin(s, o); return true;
+        case 101: cornell_box(s, o, true); return true;
+        case 102: bvh_stress(s, o); return true;
+        default: return false;
+    }
+}
+
+}  // namespace orc
