@@ -287,6 +287,15 @@ int rt_ctx_set_batch_paths(rt_ctx* ctx, uint64_t max_paths);
 int rt_ctx_set_counters(rt_ctx* ctx, int enabled);
 int rt_ctx_get_counters(rt_ctx* ctx, rt_counters* out, int reset);
 
+/* Device memory for callers that have no HIP binding of their own (the
+ * accumulation buffer `acc_colours` and the output buffers of a Camera,
+ * src/camera.rs:25-27): allocate, zero, copy in, copy out (blocking), free. */
+int rt_buffer_create(rt_ctx* ctx, size_t bytes, void** d_out);
+int rt_buffer_destroy(rt_ctx* ctx, void* d_ptr);
+int rt_buffer_zero(rt_ctx* ctx, void* d_ptr, size_t bytes);
+int rt_buffer_upload(rt_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int rt_buffer_download(rt_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
 /* Replaces World::new + the walk a Rust caller would do over its Hittable
  * tree (src/lib.rs:17-26, src/hittable.rs:35-57): copies the description,
  * bakes transforms, builds the flattened BVH and uploads everything. */
@@ -328,6 +337,22 @@ int rt_finalize(rt_ctx* ctx, const float* acc_host, uint64_t n_pixels,
  * blocking.  seed keys the medium free-path draw as in rt_render_*. */
 int rt_intersect_batch(rt_scene* scene, const rt_ray* rays, size_t n,
                        uint64_t seed, rt_hit* out);
+
+/* Replaces Material::emitted + Material::scatter (src/material.rs:65-122, with
+ * Texture::value, src/texture.rs:40-73) on caller-supplied (ray, hit record)
+ * pairs: for pair i writes the scattered ray (tmin = 1 when scatter returned
+ * Some, all zero for None), the attenuation and the emitted colour (3 floats
+ * each).  The scatter draws are keyed by the ray's rng_* fields.  Host
+ * buffers, blocking. */
+int rt_shade_batch(rt_scene* scene, const rt_ray* rays, const rt_hit* hits,
+                   size_t n, uint64_t seed, rt_ray* out_scattered,
+                   float* out_attenuation3, float* out_emitted3);
+
+/* Replaces get_ray (src/camera.rs:311-320) for the listed pixels of one sample
+ * number: the primary rays the render would start from.  Host buffers. */
+int rt_primary_rays(rt_ctx* ctx, const rt_camera_desc* cam, uint64_t seed,
+                    uint32_t sample, const uint32_t* pixels, size_t n,
+                    rt_ray* out);
 
 /* Block until all work enqueued by this context has finished. */
 int rt_ctx_synchronize(rt_ctx* ctx);

@@ -328,7 +328,7 @@ inline void earth_and_perlin(Scene& s, const BuildOptions& o) {
     uint32_t earth_material = s.push_material(Material::LAMBERTIAN, s.tex_image(o.earth));
     world.push_back(s.sphere(Vec3(0.0f, 2.0f, -4.5f), 2.0f, earth_material));
     uint32_t diff_light = s.push_material(Material::DIFFUSE_LIGHT, s.tex_colour(Vec3(4.0f, 4.0f, 4.0f)));
-    world.push_back(s.quad(Vec3(-2.0f, 7.0f, -3.0f), Vec3(4.0f, 0.0f, 0.0f), Vec3(0.0f, 0.0f, 6.0f), diff_light));
+    world.push_back(s.quad(Vec3(-4.0f, 7.0f, -6.0f), Vec3(8.0f, 0.0f, 0.0f), Vec3(0.0f, 0.0f, 12.0f), diff_light));
     size_t w, h; pick_resolution(o, 1920, 1080, w, h);
     s.camera_new(Vec3(26.0f, 3.0f, 6.0f), w, h, o.max_depth, 20.0f, Vec3(0.0f, 2.0f, 0.0f), 0.0f, 10.0f, Vec3(0, 0, 0));
     s.change_pitch_yaw_by(-2.0f, 193.0f);

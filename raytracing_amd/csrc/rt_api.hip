@@ -1,0 +1,888 @@
+// rt_api.hip — implementation of the C ABI declared in include/rt_abi.h:
+// context / scene lifetime, scene ingestion (validation, baking of Move/RotateY
+// placements, BVH build, upload) and the host side of the wavefront loop.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "rt_bvh.h"
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                \
+    } while (0)
+
+constexpr uint64_t DEFAULT_BATCH_PATHS = 16ull << 20;
+constexpr int N_PHASES = 4;
+
+struct EventPair {
+    hipEvent_t a, b;
+    int phase;
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t max_blocks = 2048;
+    uint64_t batch_paths = DEFAULT_BATCH_PATHS;
+    bool counters_on = false;
+    bool phase_timing = false;
+
+    // queues (capacity = queue_cap paths)
+    uint64_t queue_cap = 0;
+    float4* ray_o[2] = {nullptr, nullptr};
+    float4* ray_d[2] = {nullptr, nullptr};
+    float4* thr[2] = {nullptr, nullptr};
+    uint2* hits = nullptr;
+    float4* radiance = nullptr;
+    uint32_t* counts = nullptr;
+    uint32_t counts_cap = 0;
+    DCounters* d_counters = nullptr;
+
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool have_render_time = false;
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    float phase_ms[N_PHASES] = {0, 0, 0, 0};
+    uint32_t phase_launches[N_PHASES] = {0, 0, 0, 0};
+    bool phase_pending = false;
+};
+
+struct rt_scene {
+    rt_ctx* ctx = nullptr;
+    std::vector<void*> allocations;
+    DScene d{};
+    uint32_t bvh_depth = 0;
+};
+
+namespace {
+
+int set_device(const rt_ctx* ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+void free_queues(rt_ctx* c) {
+    for (int i = 0; i < 2; ++i) {
+        if (c->ray_o[i]) (void)hipFree(c->ray_o[i]);
+        if (c->ray_d[i]) (void)hipFree(c->ray_d[i]);
+        if (c->thr[i]) (void)hipFree(c->thr[i]);
+        c->ray_o[i] = c->ray_d[i] = c->thr[i] = nullptr;
+    }
+    if (c->hits) (void)hipFree(c->hits);
+    if (c->radiance) (void)hipFree(c->radiance);
+    c->hits = nullptr;
+    c->radiance = nullptr;
+    c->queue_cap = 0;
+}
+
+int ensure_queues(rt_ctx* c, uint64_t paths, uint32_t n_counts) {
+    if (paths > c->queue_cap) {
+        free_queues(c);
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipMalloc((void**)&c->ray_o[i], paths * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&c->ray_d[i], paths * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&c->thr[i], paths * sizeof(float4)));
+        }
+        HIP_TRY(hipMalloc((void**)&c->hits, paths * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void**)&c->radiance, paths * sizeof(float4)));
+        c->queue_cap = paths;
+    }
+    if (n_counts > c->counts_cap) {
+        if (c->counts) (void)hipFree(c->counts);
+        c->counts = nullptr;
+        HIP_TRY(hipMalloc((void**)&c->counts, n_counts * sizeof(uint32_t)));
+        c->counts_cap = n_counts;
+    }
+    return RT_OK;
+}
+
+// ---- per-launch phase timing ------------------------------------------------------
+int phase_begin(rt_ctx* c, int phase, EventPair** out) {
+    *out = nullptr;
+    if (!c->phase_timing) return RT_OK;
+    if (c->ev_used == c->ev_pool.size()) {
+        EventPair p{};
+        HIP_TRY(hipEventCreate(&p.a));
+        HIP_TRY(hipEventCreate(&p.b));
+        c->ev_pool.push_back(p);
+    }
+    EventPair* p = &c->ev_pool[c->ev_used++];
+    p->phase = phase;
+    HIP_TRY(hipEventRecord(p->a, c->stream));
+    *out = p;
+    return RT_OK;
+}
+int phase_end(rt_ctx* c, EventPair* p) {
+    if (p) HIP_TRY(hipEventRecord(p->b, c->stream));
+    return RT_OK;
+}
+int collect_phases(rt_ctx* c) {
+    if (!c->phase_pending) return RT_OK;
+    for (int i = 0; i < N_PHASES; ++i) { c->phase_ms[i] = 0; c->phase_launches[i] = 0; }
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b));
+        c->phase_ms[c->ev_pool[i].phase] += ms;
+        c->phase_launches[c->ev_pool[i].phase]++;
+    }
+    c->ev_used = 0;
+    c->phase_pending = false;
+    return RT_OK;
+}
+
+// ---- scene ingestion ---------------------------------------------------------------
+struct Xf {
+    double s = 0, c = 1, off[3] = {0, 0, 0};
+    bool identity = true;
+};
+
+// object -> world: p = R^-1 p' + offset, R^-1: x = cos x' + sin z', z = -sin x' + cos z'
+void rot_inv(const Xf& x, const double in[3], double out[3]) {
+    out[0] = x.c * in[0] + x.s * in[2];
+    out[1] = in[1];
+    out[2] = -x.s * in[0] + x.c * in[2];
+}
+void point_to_world(const Xf& x, const float in[3], double out[3]) {
+    double v[3] = {in[0], in[1], in[2]};
+    if (x.identity) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; return; }
+    rot_inv(x, v, out);
+    for (int a = 0; a < 3; ++a) out[a] += x.off[a];
+}
+void vec_to_world(const Xf& x, const float in[3], double out[3]) {
+    double v[3] = {in[0], in[1], in[2]};
+    if (x.identity) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; return; }
+    rot_inv(x, v, out);
+}
+
+struct Aabb {
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    void grow(const double p[3], double r = 0.0) {
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(mn[a], std::nextafter((float)(p[a] - r), -FLT_MAX));
+            mx[a] = std::max(mx[a], std::nextafter((float)(p[a] + r), FLT_MAX));
+        }
+    }
+    void grow(const Aabb& o) {
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], o.mn[a]); mx[a] = std::max(mx[a], o.mx[a]); }
+    }
+    // Keeps flat boxes (axis-aligned quads) from having zero thickness, as
+    // AABB::pad_to_minimums does (src/math/aabb.rs:79-98), scaled to the coordinates.
+    void pad() {
+        for (int a = 0; a < 3; ++a) {
+            float m = std::max(std::fabs(mn[a]), std::fabs(mx[a]));
+            float eps = std::max(5e-5f, m * 1e-6f);
+            mn[a] -= eps;
+            mx[a] += eps;
+        }
+    }
+};
+
+template <class T>
+int upload(rt_scene* sc, const std::vector<T>& host, const T** out) {
+    *out = nullptr;
+    size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    sc->allocations.push_back(d);
+    if (!host.empty()) HIP_TRY(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)d;
+    return RT_OK;
+}
+
+int validate(const rt_scene_desc* d) {
+    if (d->abi_version != RT_ABI_VERSION) return fail(RT_ERR_INVALID_ARGUMENT, "scene desc abi_version %u, library %u", d->abi_version, RT_ABI_VERSION);
+    if (d->n_materials == 0) return fail(RT_ERR_INVALID_ARGUMENT, "scene needs at least the default material (MaterialId 0)");
+    if (d->n_spheres >= MAX_PRIMS_PER_KIND || d->n_moving_spheres >= MAX_PRIMS_PER_KIND || d->n_quads >= MAX_PRIMS_PER_KIND ||
+        d->n_media >= MAX_PRIMS_PER_KIND)
+        return fail(RT_ERR_UNSUPPORTED, "more than 2^28 primitives of one kind");
+    auto need = [&](const void* p, uint32_t n, const char* what) { return n == 0 || p != nullptr ? 0 : fail(RT_ERR_INVALID_ARGUMENT, "%s is NULL but its count is %u", what, n); };
+    int e;
+    if ((e = need(d->spheres, d->n_spheres, "spheres"))) return e;
+    if ((e = need(d->moving_spheres, d->n_moving_spheres, "moving_spheres"))) return e;
+    if ((e = need(d->quads, d->n_quads, "quads"))) return e;
+    if ((e = need(d->media, d->n_media, "media"))) return e;
+    if ((e = need(d->world, d->n_world, "world"))) return e;
+    if ((e = need(d->boundary, d->n_boundary, "boundary"))) return e;
+    if ((e = need(d->transforms, d->n_transforms, "transforms"))) return e;
+    if ((e = need(d->materials, d->n_materials, "materials"))) return e;
+    if ((e = need(d->textures, d->n_textures, "textures"))) return e;
+    if ((e = need(d->images, d->n_images, "images"))) return e;
+    if ((e = need(d->perlins, d->n_perlins, "perlins"))) return e;
+    auto count_of = [&](uint32_t kind) -> int64_t {
+        switch (kind) {
+            case RT_PRIM_SPHERE: return d->n_spheres;
+            case RT_PRIM_MOVING_SPHERE: return d->n_moving_spheres;
+            case RT_PRIM_QUAD: return d->n_quads;
+            case RT_PRIM_MEDIUM: return d->n_media;
+            default: return -1;
+        }
+    };
+    for (uint32_t i = 0; i < d->n_world; ++i)
+        if ((int64_t)d->world[i].index >= count_of(d->world[i].kind)) return fail(RT_ERR_INVALID_ARGUMENT, "world[%u] references kind %u index %u out of range", i, d->world[i].kind, d->world[i].index);
+    for (uint32_t i = 0; i < d->n_boundary; ++i) {
+        if (d->boundary[i].kind == RT_PRIM_MEDIUM) return fail(RT_ERR_UNSUPPORTED, "boundary[%u]: a medium cannot bound another medium", i);
+        if ((int64_t)d->boundary[i].index >= count_of(d->boundary[i].kind)) return fail(RT_ERR_INVALID_ARGUMENT, "boundary[%u] out of range", i);
+    }
+    auto mat_ok = [&](uint32_t m) { return m < d->n_materials; };
+    auto xf_ok = [&](uint32_t t) { return t == RT_NO_TRANSFORM || t < d->n_transforms; };
+    for (uint32_t i = 0; i < d->n_spheres; ++i)
+        if (!mat_ok(d->spheres[i].material) || !xf_ok(d->spheres[i].transform) || !(d->spheres[i].radius == d->spheres[i].radius))
+            return fail(RT_ERR_INVALID_ARGUMENT, "spheres[%u]: bad material, transform or radius", i);
+    for (uint32_t i = 0; i < d->n_moving_spheres; ++i)
+        if (!mat_ok(d->moving_spheres[i].material) || !xf_ok(d->moving_spheres[i].transform)) return fail(RT_ERR_INVALID_ARGUMENT, "moving_spheres[%u]: bad material or transform", i);
+    for (uint32_t i = 0; i < d->n_quads; ++i)
+        if (!mat_ok(d->quads[i].material) || !xf_ok(d->quads[i].transform)) return fail(RT_ERR_INVALID_ARGUMENT, "quads[%u]: bad material or transform", i);
+    for (uint32_t i = 0; i < d->n_media; ++i) {
+        const rt_medium& m = d->media[i];
+        if (!mat_ok(m.phase_material) || (uint64_t)m.first_boundary + m.n_boundary > d->n_boundary || m.n_boundary == 0)
+            return fail(RT_ERR_INVALID_ARGUMENT, "media[%u]: bad phase material or boundary range", i);
+    }
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        if (d->materials[i].kind > RT_MAT_ISOTROPIC) return fail(RT_ERR_INVALID_ARGUMENT, "materials[%u]: unknown kind %u", i, d->materials[i].kind);
+        if (d->materials[i].texture >= d->n_textures) return fail(RT_ERR_INVALID_ARGUMENT, "materials[%u]: texture %u out of range", i, d->materials[i].texture);
+    }
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const rt_texture& t = d->textures[i];
+        switch (t.kind) {
+            case RT_TEX_SOLID: break;
+            case RT_TEX_CHECKER:
+                if (t.even >= d->n_textures || t.odd >= d->n_textures) return fail(RT_ERR_INVALID_ARGUMENT, "textures[%u]: checker children out of range", i);
+                break;
+            case RT_TEX_IMAGE:
+                if (t.image >= d->n_images) return fail(RT_ERR_INVALID_ARGUMENT, "textures[%u]: image %u out of range", i, t.image);
+                break;
+            case RT_TEX_NOISE:
+                if (t.perlin >= d->n_perlins) return fail(RT_ERR_INVALID_ARGUMENT, "textures[%u]: perlin %u out of range", i, t.perlin);
+                break;
+            default: return fail(RT_ERR_INVALID_ARGUMENT, "textures[%u]: unknown kind %u", i, t.kind);
+        }
+    }
+    for (uint32_t i = 0; i < d->n_images; ++i) {
+        const rt_image& im = d->images[i];
+        if (im.width == 0 || im.height == 0 || !im.texels || im.format > RT_IMAGE_RGB32F) return fail(RT_ERR_INVALID_ARGUMENT, "images[%u]: empty or unknown format", i);
+    }
+    for (uint32_t i = 0; i < d->n_perlins; ++i) {
+        const rt_perlin& p = d->perlins[i];
+        if (p.point_count == 0 || !p.rand_vecs || !p.perm_x || !p.perm_y || !p.perm_z) return fail(RT_ERR_INVALID_ARGUMENT, "perlins[%u]: empty tables", i);
+        for (uint32_t k = 0; k < p.point_count; ++k)
+            if (p.perm_x[k] >= p.point_count || p.perm_y[k] >= p.point_count || p.perm_z[k] >= p.point_count)
+                return fail(RT_ERR_INVALID_ARGUMENT, "perlins[%u]: permutation entry out of range", i);
+    }
+    return RT_OK;
+}
+
+DCamera to_dcamera(const rt_camera_desc* c) {
+    DCamera d;
+    d.centre = f3(c->centre[0], c->centre[1], c->centre[2]);
+    d.pixel00 = f3(c->pixel00_loc[0], c->pixel00_loc[1], c->pixel00_loc[2]);
+    d.du = f3(c->pixel_delta_u[0], c->pixel_delta_u[1], c->pixel_delta_u[2]);
+    d.dv = f3(c->pixel_delta_v[0], c->pixel_delta_v[1], c->pixel_delta_v[2]);
+    d.ddu = f3(c->defocus_disk_u[0], c->defocus_disk_u[1], c->defocus_disk_u[2]);
+    d.ddv = f3(c->defocus_disk_v[0], c->defocus_disk_v[1], c->defocus_disk_v[2]);
+    d.background = f3(c->background_colour[0], c->background_colour[1], c->background_colour[2]);
+    d.defocus_angle = c->defocus_angle;
+    d.width = c->width;
+    d.height = c->height;
+    d.max_depth = c->max_depth;
+    return d;
+}
+
+int check_camera(const rt_camera_desc* cam) {
+    if (!cam) return fail(RT_ERR_INVALID_ARGUMENT, "camera is NULL");
+    if (cam->width == 0 || cam->height == 0) return fail(RT_ERR_INVALID_ARGUMENT, "camera has an empty image (%ux%u)", cam->width, cam->height);
+    if ((uint64_t)cam->width * cam->height >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "image larger than 2^31 pixels");
+    if (cam->max_depth > 4096) return fail(RT_ERR_UNSUPPORTED, "max_depth above 4096");
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_last_error.c_str(); }
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_ctx_create(int device_id, rt_ctx** out) {
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available");
+    if (device_id < 0 || device_id >= n) return fail(RT_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", device_id, n - 1);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    rt_ctx* c = new rt_ctx();
+    c->device = device_id;
+    c->max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
+    hipError_t e = hipMalloc((void**)&c->d_counters, sizeof(DCounters));
+    if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(DCounters));
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(RT_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return RT_OK;
+}
+
+int rt_ctx_destroy(rt_ctx* c) {
+    if (!c) return RT_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_queues(c);
+    if (c->counts) (void)hipFree(c->counts);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    delete c;
+    return RT_OK;
+}
+
+int rt_ctx_set_stream(rt_ctx* c, void* s) {
+    if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    c->stream = (hipStream_t)s;
+    return RT_OK;
+}
+
+int rt_ctx_set_batch_paths(rt_ctx* c, uint64_t n) {
+    if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (n != 0 && n < 64) return fail(RT_ERR_INVALID_ARGUMENT, "batch of %llu paths is below one wavefront", (unsigned long long)n);
+    if (n >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "batch above 2^31 paths");
+    c->batch_paths = n ? n : DEFAULT_BATCH_PATHS;
+    return RT_OK;
+}
+
+int rt_ctx_set_counters(rt_ctx* c, int on) {
+    if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    c->counters_on = on != 0;
+    return RT_OK;
+}
+
+int rt_ctx_get_counters(rt_ctx* c, rt_counters* out, int reset) {
+    if (!c || !out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    int e = set_device(c);
+    if (e) return e;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    static_assert(sizeof(rt_counters) == sizeof(DCounters), "counter layouts differ");
+    HIP_TRY(hipMemcpy(out, c->d_counters, sizeof(DCounters), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(c->d_counters, 0, sizeof(DCounters)));
+    return RT_OK;
+}
+
+int rt_ctx_synchronize(rt_ctx* c) {
+    if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    int e = set_device(c);
+    if (e) return e;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return collect_phases(c);
+}
+
+int rt_ctx_last_render_ms(rt_ctx* c, float* ms) {
+    if (!c || !ms) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!c->have_render_time) return fail(RT_ERR_INVALID_ARGUMENT, "no render has been enqueued on this context");
+    HIP_TRY(hipEventSynchronize(c->ev_end));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev_begin, c->ev_end));
+    return RT_OK;
+}
+
+int rt_ctx_set_phase_timing(rt_ctx* c, int on) {
+    if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    c->phase_timing = on != 0;
+    return RT_OK;
+}
+
+int rt_ctx_phase_ms(rt_ctx* c, int phase, float* ms, uint32_t* launches) {
+    if (!c || phase < 0 || phase >= N_PHASES) return fail(RT_ERR_INVALID_ARGUMENT, "bad context or phase");
+    if (c->phase_pending) return fail(RT_ERR_INVALID_ARGUMENT, "call rt_ctx_synchronize before reading phase times");
+    if (ms) *ms = c->phase_ms[phase];
+    if (launches) *launches = c->phase_launches[phase];
+    return RT_OK;
+}
+
+int rt_buffer_create(rt_ctx* c, size_t bytes, void** d_out) {
+    if (!c || !d_out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    *d_out = nullptr;
+    int e = set_device(c);
+    if (e) return e;
+    HIP_TRY(hipMalloc(d_out, std::max<size_t>(bytes, 16)));
+    return RT_OK;
+}
+
+int rt_buffer_destroy(rt_ctx* c, void* d_ptr) {
+    if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (!d_ptr) return RT_OK;
+    int e = set_device(c);
+    if (e) return e;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(d_ptr));
+    return RT_OK;
+}
+
+int rt_buffer_zero(rt_ctx* c, void* d_ptr, size_t bytes) {
+    if (!c || !d_ptr) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    int e = set_device(c);
+    if (e) return e;
+    HIP_TRY(hipMemsetAsync(d_ptr, 0, bytes, c->stream));
+    return RT_OK;
+}
+
+int rt_buffer_upload(rt_ctx* c, void* d_dst, const void* src, size_t bytes) {
+    if (!c || !d_dst || !src) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    int e = set_device(c);
+    if (e) return e;
+    HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_buffer_download(rt_ctx* c, void* dst, const void* d_src, size_t bytes) {
+    if (!c || !dst || !d_src) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    int e = set_device(c);
+    if (e) return e;
+    HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return collect_phases(c);
+}
+
+int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
+    if (!ctx || !desc || !out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    int e = validate(desc);
+    if (e) return e;
+    if ((e = set_device(ctx))) return e;
+
+    std::vector<Xf> xfs(desc->n_transforms);
+    std::vector<float4> xforms(2 * (size_t)desc->n_transforms);
+    for (uint32_t i = 0; i < desc->n_transforms; ++i) {
+        const rt_transform& t = desc->transforms[i];
+        xfs[i].s = t.sin_theta; xfs[i].c = t.cos_theta; xfs[i].identity = false;
+        for (int a = 0; a < 3; ++a) xfs[i].off[a] = t.offset[a];
+        xforms[2 * (size_t)i] = make_float4(t.sin_theta, t.cos_theta, 0.0f, 0.0f);
+        xforms[2 * (size_t)i + 1] = make_float4(t.offset[0], t.offset[1], t.offset[2], 0.0f);
+    }
+    const Xf ident;
+    auto xf_of = [&](uint32_t t) -> const Xf& { return t == RT_NO_TRANSFORM ? ident : xfs[t]; };
+
+    // bake placements into world-space primitives
+    std::vector<float4> spheres(desc->n_spheres), moving(2 * (size_t)desc->n_moving_spheres), quads(4 * (size_t)desc->n_quads);
+    std::vector<uint4> sphere_meta(desc->n_spheres), moving_meta(desc->n_moving_spheres), quad_meta(desc->n_quads);
+    std::vector<Aabb> sphere_box(desc->n_spheres), moving_box(desc->n_moving_spheres), quad_box(desc->n_quads), medium_box(desc->n_media);
+    for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+        const rt_sphere& s = desc->spheres[i];
+        double c[3];
+        point_to_world(xf_of(s.transform), s.centre, c);
+        spheres[i] = make_float4(s.centre[0], s.centre[1], s.centre[2], s.radius);
+        sphere_meta[i] = make_uint4(s.material, s.prim_id, s.transform, 0);
+        sphere_box[i].grow(c, std::fabs((double)s.radius));
+        sphere_box[i].pad();
+    }
+    for (uint32_t i = 0; i < desc->n_moving_spheres; ++i) {
+        const rt_moving_sphere& s = desc->moving_spheres[i];
+        double c0[3], dc[3];
+        point_to_world(xf_of(s.transform), s.centre0, c0);
+        vec_to_world(xf_of(s.transform), s.dcentre, dc);
+        moving[2 * (size_t)i] = make_float4(s.centre0[0], s.centre0[1], s.centre0[2], s.radius);
+        moving[2 * (size_t)i + 1] = make_float4(s.dcentre[0], s.dcentre[1], s.dcentre[2], 0.0f);
+        moving_meta[i] = make_uint4(s.material, s.prim_id, s.transform, 0);
+        // union of the boxes at time 0 and 1 (src/hittable.rs:166-171)
+        double p1[3] = {c0[0] + dc[0], c0[1] + dc[1], c0[2] + dc[2]};
+        moving_box[i].grow(c0, std::fabs((double)s.radius));
+        moving_box[i].grow(p1, std::fabs((double)s.radius));
+        moving_box[i].pad();
+    }
+    for (uint32_t i = 0; i < desc->n_quads; ++i) {
+        const rt_quad& qd = desc->quads[i];
+        double q[3], u[3], v[3];
+        point_to_world(xf_of(qd.transform), qd.q, q);
+        vec_to_world(xf_of(qd.transform), qd.u, u);
+        vec_to_world(xf_of(qd.transform), qd.v, v);
+        // Per-quad constants of Quad::hit (src/hittable.rs:373-375) in the reference's f32
+        // operation order, from the object-space q, u, v.
+        const float* qf = qd.q;
+        const float* uf = qd.u;
+        const float* vf = qd.v;
+        auto crossf = [](const float* l, const float* r, float* o3) {
+            o3[0] = l[1] * r[2] - l[2] * r[1]; o3[1] = l[2] * r[0] - l[0] * r[2]; o3[2] = l[0] * r[1] - l[1] * r[0];
+        };
+        auto dotf = [](const float* l, const float* r) { return ((l[0] * r[0] + l[1] * r[1]) + l[2] * r[2]) + 0.0f; };
+        float n[3], N[3], w[3], A[3], B[3];
+        crossf(uf, vf, n);
+        float inv_len = 1.0f / std::sqrt(dotf(n, n));
+        for (int a = 0; a < 3; ++a) N[a] = inv_len * n[a];
+        float D = dotf(N, qf);
+        float inv_nn = 1.0f / dotf(n, n);
+        for (int a = 0; a < 3; ++a) w[a] = inv_nn * n[a];
+        crossf(vf, w, A);
+        crossf(w, uf, B);
+        float4* o = &quads[4 * (size_t)i];
+        o[0] = make_float4(N[0], N[1], N[2], D);
+        o[1] = make_float4(qf[0], qf[1], qf[2], __builtin_bit_cast(float, qd.material));
+        o[2] = make_float4(A[0], A[1], A[2], __builtin_bit_cast(float, qd.prim_id));
+        o[3] = make_float4(B[0], B[1], B[2], __builtin_bit_cast(float, qd.transform));
+        quad_meta[i] = make_uint4(qd.material, qd.prim_id, qd.transform, 0);
+        double corner[4][3];
+        for (int a = 0; a < 3; ++a) { corner[0][a] = q[a]; corner[1][a] = q[a] + u[a]; corner[2][a] = q[a] + v[a]; corner[3][a] = q[a] + u[a] + v[a]; }
+        for (auto& cpt : corner) quad_box[i].grow(cpt);
+        quad_box[i].pad();
+    }
+    auto box_of = [&](const rt_prim_ref& r) -> const Aabb& {
+        switch (r.kind) {
+            case RT_PRIM_SPHERE: return sphere_box[r.index];
+            case RT_PRIM_MOVING_SPHERE: return moving_box[r.index];
+            case RT_PRIM_QUAD: return quad_box[r.index];
+            default: return medium_box[r.index];
+        }
+    };
+    std::vector<DMedium> media(desc->n_media);
+    std::vector<uint32_t> boundary_refs(desc->n_boundary);
+    auto placed = [&](const rt_prim_ref& r) {
+        switch (r.kind) {
+            case RT_PRIM_SPHERE: return desc->spheres[r.index].transform != RT_NO_TRANSFORM;
+            case RT_PRIM_MOVING_SPHERE: return desc->moving_spheres[r.index].transform != RT_NO_TRANSFORM;
+            case RT_PRIM_QUAD: return desc->quads[r.index].transform != RT_NO_TRANSFORM;
+            default: return false;
+        }
+    };
+    for (uint32_t i = 0; i < desc->n_boundary; ++i) boundary_refs[i] = make_leaf(desc->boundary[i].kind, desc->boundary[i].index, placed(desc->boundary[i]));
+    for (uint32_t i = 0; i < desc->n_media; ++i) {
+        const rt_medium& m = desc->media[i];
+        media[i] = DMedium{m.first_boundary, m.n_boundary, m.neg_inv_density, m.phase_material, m.prim_id, {0, 0, 0}};
+        for (uint32_t k = 0; k < m.n_boundary; ++k) medium_box[i].grow(box_of(desc->boundary[m.first_boundary + k]));
+    }
+
+    // flattened BVH over the world leaves
+    std::vector<BuildPrim> prims(desc->n_world);
+    for (uint32_t i = 0; i < desc->n_world; ++i) {
+        const Aabb& b = box_of(desc->world[i]);
+        for (int a = 0; a < 3; ++a) { prims[i].bmin[a] = b.mn[a]; prims[i].bmax[a] = b.mx[a]; }
+        prims[i].ref = make_leaf(desc->world[i].kind, desc->world[i].index, placed(desc->world[i]));
+        for (int a = 0; a < 3; ++a)
+            if (!(b.mn[a] <= b.mx[a]) || !std::isfinite(b.mn[a]) || !std::isfinite(b.mx[a]))
+                return fail(RT_ERR_INVALID_ARGUMENT, "world[%u] has a non-finite or empty bounding box", i);
+    }
+    FlatBvh bvh = build_bvh(prims, 0);
+    if (bvh.max_depth > 62) return fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.max_depth);
+
+    std::vector<DMaterial> materials(desc->n_materials);
+    for (uint32_t i = 0; i < desc->n_materials; ++i) materials[i] = DMaterial{desc->materials[i].kind, desc->materials[i].param, desc->materials[i].texture, 0};
+    std::vector<DTexture> textures(desc->n_textures);
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        const rt_texture& t = desc->textures[i];
+        textures[i] = DTexture{t.kind, t.colour[0], t.colour[1], t.colour[2], t.scale, t.even, t.odd, t.image, t.perlin, {0, 0, 0}};
+    }
+
+    rt_scene* sc = new rt_scene();
+    sc->ctx = ctx;
+    sc->bvh_depth = bvh.max_depth;
+    auto bail = [&](int code) { rt_scene_destroy(sc); return code; };
+
+    std::vector<float4> nodes(bvh.nodes.size() / 4);
+    if (!nodes.empty()) std::memcpy(nodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
+    if ((e = upload(sc, nodes, &sc->d.nodes))) return bail(e);
+    if ((e = upload(sc, spheres, &sc->d.spheres))) return bail(e);
+    if ((e = upload(sc, sphere_meta, &sc->d.sphere_meta))) return bail(e);
+    if ((e = upload(sc, moving, &sc->d.moving))) return bail(e);
+    if ((e = upload(sc, moving_meta, &sc->d.moving_meta))) return bail(e);
+    if ((e = upload(sc, quads, &sc->d.quads))) return bail(e);
+    if ((e = upload(sc, quad_meta, &sc->d.quad_meta))) return bail(e);
+    if ((e = upload(sc, media, &sc->d.media))) return bail(e);
+    if ((e = upload(sc, boundary_refs, &sc->d.boundary_refs))) return bail(e);
+    if ((e = upload(sc, xforms, &sc->d.xforms))) return bail(e);
+    if ((e = upload(sc, materials, &sc->d.materials))) return bail(e);
+    if ((e = upload(sc, textures, &sc->d.textures))) return bail(e);
+
+    std::vector<DImage> images(desc->n_images);
+    for (uint32_t i = 0; i < desc->n_images; ++i) {
+        const rt_image& im = desc->images[i];
+        size_t n = (size_t)im.width * im.height;
+        images[i].width = im.width; images[i].height = im.height; images[i].format = im.format; images[i]._pad = 0;
+        if (im.format == RT_IMAGE_RGB8) {
+            std::vector<uchar4> px(n);
+            const uint8_t* src = (const uint8_t*)im.texels;
+            for (size_t k = 0; k < n; ++k) px[k] = make_uchar4(src[3 * k], src[3 * k + 1], src[3 * k + 2], 255);
+            const uchar4* dptr;
+            if ((e = upload(sc, px, &dptr))) return bail(e);
+            images[i].texels = dptr;
+        } else {
+            std::vector<float4> px(n);
+            const float* src = (const float*)im.texels;
+            for (size_t k = 0; k < n; ++k) px[k] = make_float4(src[3 * k], src[3 * k + 1], src[3 * k + 2], 0.0f);
+            const float4* dptr;
+            if ((e = upload(sc, px, &dptr))) return bail(e);
+            images[i].texels = dptr;
+        }
+    }
+    if ((e = upload(sc, images, &sc->d.images))) return bail(e);
+
+    std::vector<DPerlin> perlins(desc->n_perlins);
+    for (uint32_t i = 0; i < desc->n_perlins; ++i) {
+        const rt_perlin& p = desc->perlins[i];
+        std::vector<float4> vecs(p.point_count);
+        std::vector<uint32_t> perm(3 * (size_t)p.point_count);
+        for (uint32_t k = 0; k < p.point_count; ++k) {
+            vecs[k] = make_float4(p.rand_vecs[3 * k], p.rand_vecs[3 * k + 1], p.rand_vecs[3 * k + 2], 0.0f);
+            perm[k] = p.perm_x[k];
+            perm[p.point_count + k] = p.perm_y[k];
+            perm[2 * (size_t)p.point_count + k] = p.perm_z[k];
+        }
+        if ((e = upload(sc, vecs, &perlins[i].vecs))) return bail(e);
+        if ((e = upload(sc, perm, &perlins[i].perm))) return bail(e);
+        perlins[i].point_count = p.point_count;
+        perlins[i]._pad = 0;
+    }
+    if ((e = upload(sc, perlins, &sc->d.perlins))) return bail(e);
+
+    sc->d.root = bvh.root;
+    sc->d.n_nodes = bvh.n_nodes;
+    sc->d.n_media = desc->n_media;
+    sc->d.n_materials = desc->n_materials;
+    *out = sc;
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* sc) {
+    if (!sc) return RT_OK;
+    (void)hipSetDevice(sc->ctx->device);
+    (void)hipStreamSynchronize(sc->ctx->stream);
+    for (void* p : sc->allocations) (void)hipFree(p);
+    delete sc;
+    return RT_OK;
+}
+
+int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, uint32_t first_sample, uint32_t n_samples,
+                                float* d_acc) {
+    if (!sc || !d_acc) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    int e = check_camera(cam);
+    if (e) return e;
+    rt_ctx* c = sc->ctx;
+    if ((e = set_device(c))) return e;
+    if ((uint64_t)first_sample + n_samples > 0xFFFFFFFFull) return fail(RT_ERR_INVALID_ARGUMENT, "sample numbers overflow 32 bits");
+    const uint64_t npix = (uint64_t)cam->width * cam->height;
+    const uint32_t chunk_pixels = (uint32_t)std::min<uint64_t>(npix, c->batch_paths);
+    uint32_t spb = 1;  // samples per batch
+    if (chunk_pixels == npix) spb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->batch_paths / npix, n_samples));
+    const uint32_t n_counts = cam->max_depth + 2;
+    if ((e = ensure_queues(c, (uint64_t)chunk_pixels * spb, n_counts))) return e;
+    if ((e = collect_phases(c))) return e;
+    DCamera dcam = to_dcamera(cam);
+    DCounters* counters = c->counters_on ? c->d_counters : nullptr;
+
+    HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
+    for (uint64_t p0 = 0; p0 < npix; p0 += chunk_pixels) {
+        const uint32_t np = (uint32_t)std::min<uint64_t>(chunk_pixels, npix - p0);
+        for (uint32_t s0 = 0; s0 < n_samples; s0 += spb) {
+            const uint32_t ns = std::min(spb, n_samples - s0);
+            BatchInfo b{(uint32_t)p0, np, first_sample + s0, ns};
+            const uint32_t total = np * ns;
+            EventPair* ep;
+            if ((e = phase_begin(c, 0, &ep))) return e;
+            launch_raygen(c->stream, c->max_blocks, dcam, b, seed, c->ray_o[0], c->ray_d[0], c->thr[0], c->counts, n_counts);
+            if ((e = phase_end(c, ep))) return e;
+            int cur = 0;
+            for (uint32_t bounce = 0; bounce < cam->max_depth; ++bounce) {
+                if ((e = phase_begin(c, 1, &ep))) return e;
+                launch_extend(c->stream, c->max_blocks, total, sc->d, b, seed, bounce, c->counts, c->ray_o[cur], c->ray_d[cur], c->hits, counters);
+                if ((e = phase_end(c, ep))) return e;
+                if ((e = phase_begin(c, 2, &ep))) return e;
+                launch_shade(c->stream, c->max_blocks, total, sc->d, dcam, b, seed, bounce, c->counts, c->ray_o[cur], c->ray_d[cur],
+                             c->thr[cur], c->hits, c->ray_o[cur ^ 1], c->ray_d[cur ^ 1], c->thr[cur ^ 1], c->radiance);
+                if ((e = phase_end(c, ep))) return e;
+                cur ^= 1;
+            }
+            if (cam->max_depth == 0) HIP_TRY(hipMemsetAsync(c->radiance, 0, (size_t)total * sizeof(float4), c->stream));
+            if ((e = phase_begin(c, 3, &ep))) return e;
+            launch_accumulate(c->stream, c->max_blocks, b, c->radiance, (float4*)d_acc);
+            if ((e = phase_end(c, ep))) return e;
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev_end, c->stream));
+    HIP_TRY(hipGetLastError());
+    c->have_render_time = true;
+    c->phase_pending = c->phase_timing;
+    if (c->counters_on) {
+        // paths started: one per (pixel, sample)
+        unsigned long long add = npix * n_samples;
+        DCounters h;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(&h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+        h.samples += add;
+        HIP_TRY(hipMemcpy(c->d_counters, &h, sizeof(h), hipMemcpyHostToDevice));
+    }
+    return RT_OK;
+}
+
+int rt_render_accumulate(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, uint32_t first_sample, uint32_t n_samples,
+                         float* acc_host) {
+    if (!sc || !acc_host) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    int e = check_camera(cam);
+    if (e) return e;
+    rt_ctx* c = sc->ctx;
+    if ((e = set_device(c))) return e;
+    size_t bytes = (size_t)cam->width * cam->height * 4 * sizeof(float);
+    float* d_acc = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_acc, bytes));
+    hipError_t he = hipMemcpyAsync(d_acc, acc_host, bytes, hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess) {
+        e = rt_render_accumulate_device(sc, cam, seed, first_sample, n_samples, d_acc);
+        if (e == RT_OK) he = hipMemcpyAsync(acc_host, d_acc, bytes, hipMemcpyDeviceToHost, c->stream);
+    }
+    hipError_t hs = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_acc);
+    if (e) return e;
+    if (he != hipSuccess) return fail(RT_ERR_HIP, "accumulation buffer copy failed: %s", hipGetErrorString(he));
+    if (hs != hipSuccess) return fail(RT_ERR_HIP, "render failed: %s", hipGetErrorString(hs));
+    return collect_phases(c);
+}
+
+int rt_finalize_device(rt_ctx* c, const float* d_acc, uint64_t n_pixels, uint32_t total_samples, int mode, float exposure, void* d_out) {
+    if (!c || !d_acc || !d_out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (mode < RT_FINALIZE_MEAN || mode > RT_FINALIZE_TONEMAP_RGBA) return fail(RT_ERR_INVALID_ARGUMENT, "unknown finalize mode %d", mode);
+    if (total_samples == 0) return fail(RT_ERR_INVALID_ARGUMENT, "total_samples is 0");
+    int e = set_device(c);
+    if (e) return e;
+    float inv = 1.0f / (float)total_samples;  // src/camera.rs:279
+    launch_finalize(c->stream, c->max_blocks, (const float4*)d_acc, n_pixels, inv, mode, exposure, d_out);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_finalize(rt_ctx* c, const float* acc_host, uint64_t n_pixels, uint32_t total_samples, int mode, float exposure, void* out_host) {
+    if (!c || !acc_host || !out_host) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    int e = set_device(c);
+    if (e) return e;
+    size_t in_bytes = n_pixels * 4 * sizeof(float);
+    size_t out_bytes = mode == RT_FINALIZE_TONEMAP_RGBA ? n_pixels * sizeof(uint32_t) : in_bytes;
+    float* d_acc = nullptr;
+    void* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_acc, std::max<size_t>(in_bytes, 16)));
+    hipError_t he = hipMalloc(&d_out, std::max<size_t>(out_bytes, 16));
+    if (he != hipSuccess) { (void)hipFree(d_acc); return fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc failed: %s", hipGetErrorString(he)); }
+    he = hipMemcpyAsync(d_acc, acc_host, in_bytes, hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess) {
+        e = rt_finalize_device(c, d_acc, n_pixels, total_samples, mode, exposure, d_out);
+        if (e == RT_OK) he = hipMemcpyAsync(out_host, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+    }
+    hipError_t hs = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_acc);
+    (void)hipFree(d_out);
+    if (e) return e;
+    if (he != hipSuccess || hs != hipSuccess) return fail(RT_ERR_HIP, "finalize failed: %s", hipGetErrorString(he != hipSuccess ? he : hs));
+    return RT_OK;
+}
+
+int rt_intersect_batch(rt_scene* sc, const rt_ray* rays, size_t n, uint64_t seed, rt_hit* out) {
+    if (!sc || (n && (!rays || !out))) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n == 0) return RT_OK;
+    rt_ctx* c = sc->ctx;
+    int e = set_device(c);
+    if (e) return e;
+    rt_ray* d_rays = nullptr;
+    rt_hit* d_hits = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rays, n * sizeof(rt_ray)));
+    hipError_t he = hipMalloc((void**)&d_hits, n * sizeof(rt_hit));
+    if (he != hipSuccess) { (void)hipFree(d_rays); return fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc failed: %s", hipGetErrorString(he)); }
+    he = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess) {
+        launch_intersect(c->stream, c->max_blocks, sc->d, seed, d_rays, n, d_hits);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(out, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, c->stream);
+    hipError_t hs = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_rays);
+    (void)hipFree(d_hits);
+    if (he != hipSuccess || hs != hipSuccess) return fail(RT_ERR_HIP, "intersect failed: %s", hipGetErrorString(he != hipSuccess ? he : hs));
+    return RT_OK;
+}
+
+int rt_shade_batch(rt_scene* sc, const rt_ray* rays, const rt_hit* hits, size_t n, uint64_t seed, rt_ray* out_scattered,
+                   float* out_attenuation3, float* out_emitted3) {
+    if (!sc || (n && (!rays || !hits || !out_scattered || !out_attenuation3 || !out_emitted3))) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n == 0) return RT_OK;
+    for (size_t i = 0; i < n; ++i)
+        if (hits[i].material >= sc->d.n_materials) return fail(RT_ERR_INVALID_ARGUMENT, "hits[%zu].material %u out of range", i, hits[i].material);
+    rt_ctx* c = sc->ctx;
+    int e = set_device(c);
+    if (e) return e;
+    rt_ray *d_rays = nullptr, *d_out = nullptr;
+    rt_hit* d_hits = nullptr;
+    float *d_att = nullptr, *d_emit = nullptr;
+    hipError_t he = hipMalloc((void**)&d_rays, n * sizeof(rt_ray));
+    if (he == hipSuccess) he = hipMalloc((void**)&d_out, n * sizeof(rt_ray));
+    if (he == hipSuccess) he = hipMalloc((void**)&d_hits, n * sizeof(rt_hit));
+    if (he == hipSuccess) he = hipMalloc((void**)&d_att, n * 3 * sizeof(float));
+    if (he == hipSuccess) he = hipMalloc((void**)&d_emit, n * 3 * sizeof(float));
+    if (he == hipSuccess) he = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_hits, hits, n * sizeof(rt_hit), hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess) {
+        launch_shade_records(c->stream, c->max_blocks, sc->d, seed, d_rays, d_hits, n, d_out, d_att, d_emit);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(out_scattered, d_out, n * sizeof(rt_ray), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(out_attenuation3, d_att, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(out_emitted3, d_emit, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    hipError_t hs = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_rays); (void)hipFree(d_out); (void)hipFree(d_hits); (void)hipFree(d_att); (void)hipFree(d_emit);
+    if (he != hipSuccess || hs != hipSuccess) return fail(RT_ERR_HIP, "shade failed: %s", hipGetErrorString(he != hipSuccess ? he : hs));
+    return RT_OK;
+}
+
+int rt_primary_rays(rt_ctx* c, const rt_camera_desc* cam, uint64_t seed, uint32_t sample, const uint32_t* pixels, size_t n, rt_ray* out) {
+    if (!c || (n && (!pixels || !out))) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    int e = check_camera(cam);
+    if (e) return e;
+    if (n == 0) return RT_OK;
+    const uint64_t npix = (uint64_t)cam->width * cam->height;
+    for (size_t i = 0; i < n; ++i)
+        if (pixels[i] >= npix) return fail(RT_ERR_INVALID_ARGUMENT, "pixels[%zu] = %u outside the %ux%u image", i, pixels[i], cam->width, cam->height);
+    if ((e = set_device(c))) return e;
+    uint32_t* d_pix = nullptr;
+    rt_ray* d_out = nullptr;
+    hipError_t he = hipMalloc((void**)&d_pix, n * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMalloc((void**)&d_out, n * sizeof(rt_ray));
+    if (he == hipSuccess) he = hipMemcpyAsync(d_pix, pixels, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess) {
+        launch_primary_rays(c->stream, c->max_blocks, to_dcamera(cam), seed, sample, d_pix, n, d_out);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(out, d_out, n * sizeof(rt_ray), hipMemcpyDeviceToHost, c->stream);
+    hipError_t hs = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_pix); (void)hipFree(d_out);
+    if (he != hipSuccess || hs != hipSuccess) return fail(RT_ERR_HIP, "primary rays failed: %s", hipGetErrorString(he != hipSuccess ? he : hs));
+    return RT_OK;
+}
+
+}  // extern "C"

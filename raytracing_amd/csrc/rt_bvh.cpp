@@ -1,0 +1,188 @@
+// rt_bvh.cpp — binned-SAH BVH2 builder producing the 64-byte node layout of
+// rt_device.h.  One primitive per leaf; the n-1 inner nodes of an n-leaf tree
+// are preallocated and handed out through an atomic counter so that subtrees can
+// be built by several host threads.
+#include "rt_bvh.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace rt {
+namespace {
+
+constexpr int NBINS = 16;
+
+struct Box {
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    float mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    void grow(const float* bmin, const float* bmax) {
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], bmin[a]); mx[a] = std::max(mx[a], bmax[a]); }
+    }
+    void grow(const Box& b) { grow(b.mn, b.mx); }
+    void grow_point(const float* p) { grow(p, p); }
+    float half_area() const {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+inline void centroid(const BuildPrim& p, float* c) {
+    for (int a = 0; a < 3; ++a) c[a] = 0.5f * (p.bmin[a] + p.bmax[a]);
+}
+
+struct Builder {
+    std::vector<BuildPrim>& prims;
+    float* nodes;
+    std::atomic<uint32_t> next_node{0};
+    std::atomic<uint32_t> max_depth{0};
+
+    struct Task { size_t begin, end; uint32_t node; uint32_t depth; };
+
+    explicit Builder(std::vector<BuildPrim>& p, float* n) : prims(p), nodes(n) {}
+
+    Box bounds(size_t b, size_t e) const {
+        Box bx;
+        for (size_t i = b; i < e; ++i) bx.grow(prims[i].bmin, prims[i].bmax);
+        return bx;
+    }
+
+    // Chooses the split of [b, e) and partitions; returns the middle index.
+    size_t split(size_t b, size_t e, uint32_t depth) {
+        Box cb;
+        for (size_t i = b; i < e; ++i) { float c[3]; centroid(prims[i], c); cb.grow_point(c); }
+        float best_cost = FLT_MAX;
+        int best_axis = -1, best_bin = -1;
+        // past depth 40 split by count so that the traversal stack (64 entries) always suffices
+        for (int axis = 0; axis < 3 && depth < 40; ++axis) {
+            float lo = cb.mn[axis], hi = cb.mx[axis];
+            if (!(hi > lo)) continue;
+            float scale = (float)NBINS / (hi - lo);
+            Box bb[NBINS];
+            size_t cnt[NBINS] = {0};
+            for (size_t i = b; i < e; ++i) {
+                float c = 0.5f * (prims[i].bmin[axis] + prims[i].bmax[axis]);
+                int k = std::min(NBINS - 1, std::max(0, (int)((c - lo) * scale)));
+                bb[k].grow(prims[i].bmin, prims[i].bmax);
+                cnt[k]++;
+            }
+            float right_area[NBINS];
+            size_t right_cnt[NBINS];
+            Box acc;
+            size_t c = 0;
+            for (int k = NBINS - 1; k > 0; --k) { acc.grow(bb[k]); c += cnt[k]; right_area[k] = acc.half_area(); right_cnt[k] = c; }
+            Box left;
+            size_t lc = 0;
+            for (int k = 0; k < NBINS - 1; ++k) {
+                left.grow(bb[k]); lc += cnt[k];
+                if (lc == 0 || right_cnt[k + 1] == 0) continue;
+                float cost = left.half_area() * (float)lc + right_area[k + 1] * (float)right_cnt[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = k; }
+            }
+        }
+        size_t mid;
+        if (best_axis < 0) {
+            // coincident centroids or depth cap: median split along the widest centroid axis
+            int axis = 0;
+            for (int a = 1; a < 3; ++a) if (cb.mx[a] - cb.mn[a] > cb.mx[axis] - cb.mn[axis]) axis = a;
+            mid = b + (e - b) / 2;
+            std::nth_element(prims.begin() + (ptrdiff_t)b, prims.begin() + (ptrdiff_t)mid, prims.begin() + (ptrdiff_t)e,
+                             [axis](const BuildPrim& x, const BuildPrim& y) { return x.bmin[axis] + x.bmax[axis] < y.bmin[axis] + y.bmax[axis]; });
+        } else {
+            float lo = cb.mn[best_axis], hi = cb.mx[best_axis];
+            float scale = (float)NBINS / (hi - lo);
+            auto it = std::partition(prims.begin() + (ptrdiff_t)b, prims.begin() + (ptrdiff_t)e, [&](const BuildPrim& p) {
+                float c = 0.5f * (p.bmin[best_axis] + p.bmax[best_axis]);
+                int k = std::min(NBINS - 1, std::max(0, (int)((c - lo) * scale)));
+                return k <= best_bin;
+            });
+            mid = (size_t)(it - prims.begin());
+            if (mid == b || mid == e) mid = b + (e - b) / 2;
+        }
+        return mid;
+    }
+
+    void write_child(uint32_t node, int side, const Box& bx, uint32_t ref) {
+        float* n = nodes + 16 * (size_t)node;
+        if (side == 0) {
+            n[0] = bx.mn[0]; n[1] = bx.mn[1]; n[2] = bx.mn[2]; n[3] = bx.mx[0]; n[4] = bx.mx[1]; n[5] = bx.mx[2];
+        } else {
+            n[6] = bx.mn[0]; n[7] = bx.mn[1]; n[8] = bx.mn[2]; n[9] = bx.mx[0]; n[10] = bx.mx[1]; n[11] = bx.mx[2];
+        }
+        std::memcpy(&n[12 + side], &ref, 4);
+    }
+
+    // Fills node `node` for range [b, e), e - b >= 2.  With `deferred` set, subranges of at
+    // most `spawn_above` primitives are queued there (to be built by worker threads)
+    // instead of being recursed into.
+    void build_node(uint32_t node, size_t b, size_t e, uint32_t depth, size_t spawn_above, std::vector<Task>* deferred) {
+        uint32_t d = max_depth.load(std::memory_order_relaxed);
+        while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
+        size_t mid = split(b, e, depth);
+        float* n = nodes + 16 * (size_t)node;
+        n[14] = 0.0f; n[15] = 0.0f;
+        size_t rb[2] = {b, mid}, re[2] = {mid, e};
+        for (int side = 0; side < 2; ++side) {
+            size_t cnt = re[side] - rb[side];
+            Box bx = bounds(rb[side], re[side]);
+            if (cnt == 1) {
+                write_child(node, side, bx, prims[rb[side]].ref);
+            } else {
+                uint32_t child = next_node.fetch_add(1);
+                write_child(node, side, bx, child);
+                if (deferred && cnt <= spawn_above) deferred->push_back(Task{rb[side], re[side], child, depth + 1});
+                else build_node(child, rb[side], re[side], depth + 1, spawn_above, deferred);
+            }
+        }
+    }
+};
+
+}  // namespace
+
+FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads) {
+    FlatBvh out;
+    const size_t n = prims.size();
+    if (n == 0) return out;
+    if (n == 1) {
+        // one node whose right slot is empty (inverted box never passes the slab test)
+        out.nodes.assign(16, 0.0f);
+        float* nd = out.nodes.data();
+        for (int a = 0; a < 3; ++a) { nd[a] = prims[0].bmin[a]; nd[3 + a] = prims[0].bmax[a]; nd[6 + a] = FLT_MAX; nd[9 + a] = -FLT_MAX; }
+        uint32_t none = 0xFFFFFFFFu;
+        std::memcpy(&nd[12], &prims[0].ref, 4);
+        std::memcpy(&nd[13], &none, 4);
+        out.root = 0; out.n_nodes = 1; out.max_depth = 1;
+        return out;
+    }
+    out.nodes.assign(16 * (n - 1), 0.0f);
+    Builder bld(prims, out.nodes.data());
+    uint32_t root = bld.next_node.fetch_add(1);
+    if (threads <= 0) threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (threads == 1 || n < 200000) {
+        bld.build_node(root, 0, n, 1, 0, nullptr);
+    } else {
+        std::vector<Builder::Task> tasks;
+        bld.build_node(root, 0, n, 1, n / (size_t)(threads * 8), &tasks);
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= tasks.size()) break;
+                bld.build_node(tasks[i].node, tasks[i].begin, tasks[i].end, tasks[i].depth, 0, nullptr);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+    }
+    out.root = root;
+    out.n_nodes = bld.next_node.load();
+    out.max_depth = bld.max_depth.load();
+    return out;
+}
+
+}  // namespace rt

@@ -1,0 +1,166 @@
+// rt_device.h — device-side data layout and math/RNG helpers of the gfx950
+// path-tracing backend.  Included by the kernels (device code) and by the host
+// code that fills the buffers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_HD __host__ __device__ __forceinline__
+#define RT_D __device__ __forceinline__
+
+namespace rt {
+
+// ---------------------------------------------------------------------------
+// Leaf / child references.  bit 31 set: leaf, bits 29..30 leaf kind (the
+// rt_prim_kind values), bit 28 "placed" (the leaf is stored in object space and
+// carries a Move/RotateY placement), bits 0..27 index into that kind's array.
+// bit 31 clear: index of an inner BVH node.  REF_NONE: empty slot.
+// ---------------------------------------------------------------------------
+static constexpr uint32_t REF_LEAF = 0x80000000u;
+static constexpr uint32_t REF_PLACED = 0x10000000u;
+static constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
+static constexpr uint32_t MAX_PRIMS_PER_KIND = 1u << 28;
+static constexpr uint32_t KIND_SPHERE = 0, KIND_MOVING = 1, KIND_QUAD = 2, KIND_MEDIUM = 3;
+RT_HD uint32_t make_leaf(uint32_t kind, uint32_t index, bool placed) { return REF_LEAF | (kind << 29) | (placed ? REF_PLACED : 0u) | index; }
+RT_HD bool ref_is_leaf(uint32_t r) { return (r & REF_LEAF) != 0; }
+RT_HD uint32_t ref_kind(uint32_t r) { return (r >> 29) & 3u; }
+RT_HD uint32_t ref_index(uint32_t r) { return r & 0x0FFFFFFFu; }
+RT_HD bool ref_placed(uint32_t r) { return (r & REF_PLACED) != 0; }
+
+// ---------------------------------------------------------------------------
+// HBM layout (all arrays 16-byte aligned, one or more float4 per element):
+//   nodes   4 x float4 per BVH2 node (64 B):
+//             [0] = l.min.xyz, l.max.x   [1] = l.max.yz, r.min.xy
+//             [2] = r.min.z, r.max.xyz   [3] = bits(left ref), bits(right ref), 0, 0
+//   spheres 1 x float4: centre.xyz, radius                      (16 B)
+//   moving  2 x float4: centre0.xyz, radius | dcentre.xyz, 0     (32 B)
+//   quads   4 x float4: N.xyz, D | q.xyz, bits(material) |
+//                       A.xyz, bits(prim_id) | B.xyz, bits(transform)  (64 B)
+//           N = unit(u x v), D = N.q, w = n/(n.n), A = v x w, B = w x u so that
+//           alpha = (p-q).A and beta = (p-q).B (src/hittable.rs:372-408)
+//   *_meta  uint4: material, prim_id, transform (or RT_NO_TRANSFORM), 0
+//   xforms  2 x float4 per placement: sin, cos, 0, 0 | offset.xyz, 0
+// A leaf wrapped in Move/RotateY stays in object space; the ray is taken into
+// object space at the leaf exactly as Ray::hit_anything does (src/math/ray.rs:207-247),
+// which keeps hit distances bit-identical to the reference's.  Its BVH box is
+// the world-space box of the placed leaf.
+// ---------------------------------------------------------------------------
+struct DMedium {
+    uint32_t first_boundary, n_boundary;
+    float neg_inv_density;
+    uint32_t phase_material;
+    uint32_t prim_id;
+    uint32_t _pad[3];
+};
+
+struct DMaterial {
+    uint32_t kind;
+    float param;
+    uint32_t texture;
+    uint32_t _pad;
+};
+
+struct DTexture {
+    uint32_t kind;
+    float r, g, b;
+    float scale;
+    uint32_t even, odd;
+    uint32_t image, perlin;
+    uint32_t _pad[3];
+};
+
+struct DImage {
+    const void* texels;  // uchar4 (RGBX) or float4 per texel
+    uint32_t width, height;
+    uint32_t format;     // rt_image_format
+    uint32_t _pad;
+};
+
+struct DPerlin {
+    const float4* vecs;      // point_count unit vectors (xyz, 0)
+    const uint32_t* perm;    // 3 * point_count: x | y | z
+    uint32_t point_count;
+    uint32_t _pad;
+};
+
+struct DScene {
+    const float4* nodes;
+    const float4* spheres;
+    const uint4* sphere_meta;
+    const float4* moving;
+    const uint4* moving_meta;
+    const float4* quads;
+    const uint4* quad_meta;
+    const DMedium* media;
+    const uint32_t* boundary_refs;
+    const float4* xforms;      // 2 x float4 per placement
+    const DMaterial* materials;
+    const DTexture* textures;
+    const DImage* images;
+    const DPerlin* perlins;
+    uint32_t root;             // child reference of the whole world (REF_NONE when empty)
+    uint32_t n_nodes;
+    uint32_t n_media;
+    uint32_t n_materials;
+};
+
+struct DCamera {
+    float3 centre, pixel00, du, dv, ddu, ddv, background;
+    float defocus_angle;
+    uint32_t width, height, max_depth;
+};
+
+struct DCounters {
+    unsigned long long samples, segments, node_visits, sphere_tests, quad_tests, medium_tests, hits, _pad;
+};
+
+// ---------------------------------------------------------------------------
+// float3 helpers (HIP's float3 already has the component-wise operators)
+// ---------------------------------------------------------------------------
+RT_HD float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
+RT_HD float3 f3(float4 v) { return make_float3(v.x, v.y, v.z); }
+RT_HD float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_HD float3 cross3(float3 l, float3 r) {
+    return f3(l.y * r.z - l.z * r.y, l.z * r.x - l.x * r.z, l.x * r.y - l.y * r.x);
+}
+RT_HD float len3(float3 a) { return sqrtf(dot3(a, a)); }
+RT_HD float3 unit3(float3 a) { return (1.0f / len3(a)) * a; }
+
+// ---------------------------------------------------------------------------
+// Counter-based random numbers: a pure function of
+// (seed, pixel, sample, bounce, stream); draws inside one (bounce, stream) are
+// sequential xoroshiro64**.  Replaces the per-row xoshiro256++ stream of
+// src/rng.rs:17-60 / src/camera.rs:287 so that results do not depend on the
+// order in which rays are processed.
+// ---------------------------------------------------------------------------
+static constexpr uint32_t STREAM_CAMERA = 0, STREAM_SCATTER = 1, STREAM_MEDIUM0 = 2;
+
+RT_HD uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+RT_HD uint64_t path_key(uint64_t seed, uint32_t pixel, uint32_t sample) {
+    return mix64(seed + 0x9E3779B97F4A7C15ull * (((uint64_t)pixel << 32) | sample));
+}
+struct Rng {
+    uint32_t s0, s1;
+    RT_HD void init(uint64_t pkey, uint32_t bounce, uint32_t stream) {
+        uint64_t b = mix64(pkey ^ (0xD1B54A32D192ED03ull * ((((uint64_t)bounce << 32) | stream) + 1ull)));
+        s0 = (uint32_t)b;
+        s1 = (uint32_t)(b >> 32);
+        if ((s0 | s1) == 0u) s0 = 0x9E3779B9u;
+    }
+    RT_HD static uint32_t rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+    RT_HD uint32_t next_u32() {
+        uint32_t r = rotl(s0 * 0x9E3779BBu, 5) * 5u;
+        s1 ^= s0;
+        s0 = rotl(s0, 26) ^ s1 ^ (s1 << 9);
+        s1 = rotl(s1, 13);
+        return r;
+    }
+    RT_HD float next() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
+};
+
+}  // namespace rt

@@ -1,0 +1,36 @@
+// rt_kernels.h — host-callable launchers of the kernels in rt_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_abi.h"
+#include "rt_device.h"
+
+namespace rt {
+
+// One batch of paths: pixels [first_pixel, first_pixel + n_pixels) of the image,
+// sample numbers [first_sample, first_sample + n_samples).
+struct BatchInfo {
+    uint32_t first_pixel, n_pixels, first_sample, n_samples;
+};
+
+// max_blocks caps the grid (grid-stride kernels); upper_bound is a host-side
+// bound on the queue length, the exact length is read from counts[bounce].
+void launch_raygen(hipStream_t st, uint32_t max_blocks, const DCamera& cam, const BatchInfo& b, uint64_t seed, float4* ray_o, float4* ray_d,
+                   float4* thr, uint32_t* counts, uint32_t n_counts);
+void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam, uint64_t seed, uint32_t sample, const uint32_t* pixels,
+                         unsigned long long n, rt_ray* out);
+void launch_extend(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
+                   uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits, DCounters* counters);
+void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const DCamera& cam, const BatchInfo& b,
+                  uint64_t seed, uint32_t bounce, uint32_t* counts, const float4* ray_o, const float4* ray_d, const float4* thr,
+                  const uint2* hits, float4* out_o, float4* out_d, float4* out_thr, float4* radiance);
+void launch_accumulate(hipStream_t st, uint32_t max_blocks, const BatchInfo& b, const float4* radiance, float4* acc);
+void launch_finalize(hipStream_t st, uint32_t max_blocks, const float4* acc, unsigned long long n_pixels, float inv_samples, int mode,
+                     float exposure, void* out);
+void launch_intersect(hipStream_t st, uint32_t max_blocks, const DScene& sc, uint64_t seed, const rt_ray* rays, unsigned long long n,
+                      rt_hit* out);
+void launch_shade_records(hipStream_t st, uint32_t max_blocks, const DScene& sc, uint64_t seed, const rt_ray* rays, const rt_hit* hits,
+                          unsigned long long n, rt_ray* out_rays, float* out_att, float* out_emit);
+
+}  // namespace rt

@@ -1,0 +1,827 @@
+// rt_kernels.hip — gfx950 kernels of the wavefront path tracer.
+//
+// One sample of one pixel is a "path"; a path is advanced one segment per
+// bounce by two kernels that stream compacted queues through HBM:
+//
+//   raygen      get_ray (src/camera.rs:311-320,368-380)          -> ray queue
+//   extend      Ray::hit_anything (src/math/ray.rs:59-275): flattened-BVH closest
+//               hit incl. constant media                          -> hit records
+//   shade       ray_colour's loop body (src/camera.rs:339-364): Material::emitted /
+//               scatter (src/material.rs:65-122), Texture::value (src/texture.rs:40-73),
+//               PerlinNoise (src/perlin_noise.rs:39-102); finished paths write
+//               their radiance, the rest are appended to the next ray queue
+//   accumulate  acc[pixel] += radiance, in sample order (src/camera.rs:295-296)
+//   finalize    the hdr / realtime per-pixel closures (src/camera.rs:95-100,115-118)
+//
+// Queue records are float4 / uint2 arrays indexed by queue slot, so every wave
+// access is a contiguous 1 KiB (float4) or 512 B (uint2) segment.
+#include <hip/hip_runtime.h>
+
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+// Leaf tests, ray generation and shading keep the reference's operation order
+// (rustc never fuses a*b+c), so that hit distances and scattered rays agree with
+// the reference's f32 results bit for bit wherever the same inputs are used.
+// Only the BVH slab test, which culls but never decides a result, is contracted.
+#pragma clang fp contract(off)
+
+namespace rt {
+
+static constexpr float RT_INF = __builtin_huge_valf();
+static constexpr int STACK_SIZE = 64;
+
+// ---------------------------------------------------------------------------
+// leaf tests
+// ---------------------------------------------------------------------------
+
+// Sphere::hit / MovingSphere::hit root selection (src/hittable.rs:262-279):
+// oc = origin - centre, open interval tmin < root < tmax.
+RT_D bool sphere_root(float3 centre, float radius, float3 o, float3 d, float a, float tmin, float tmax, float& t) {
+    float3 oc = o - centre;
+    float half_b = dot3(oc, d);
+    float c = dot3(oc, oc) - radius * radius;
+    float disc = half_b * half_b - a * c;
+    if (disc < 0.0f) return false;
+    float sq = sqrtf(disc);
+    float root = (-half_b - sq) / a;
+    if (!(tmin < root && root < tmax)) {
+        root = (-half_b + sq) / a;
+        if (!(tmin < root && root < tmax)) return false;
+    }
+    t = root;
+    return true;
+}
+
+// Quad::hit (src/hittable.rs:372-398) with the per-quad constants hoisted:
+// closed interval tmin <= t <= tmax, 0 <= alpha, beta <= 1.
+RT_D bool quad_root(const float4* __restrict__ q4, float3 o, float3 d, float tmin, float tmax, float& t) {
+    float4 nd = q4[0];
+    float3 N = f3(nd);
+    float denom = dot3(N, d);
+    if (fabsf(denom) < 1e-8f) return false;
+    float tt = (nd.w - dot3(N, o)) / denom;
+    if (!(tmin <= tt && tt <= tmax)) return false;
+    float4 qq = q4[1], A = q4[2], B = q4[3];
+    float3 h = (o + tt * d) - f3(qq);
+    float alpha = dot3(h, f3(A));
+    float beta = dot3(h, f3(B));
+    if (!(0.0f <= alpha && alpha <= 1.0f && 0.0f <= beta && beta <= 1.0f)) return false;
+    t = tt;
+    return true;
+}
+
+struct Probe {  // per-thread work counters (only live in the counting build)
+    uint32_t nodes = 0, spheres = 0, quads = 0, media = 0;
+};
+
+// Move { RotateY { obj } } entry (src/math/ray.rs:207-229): origin - offset, then
+// x' = cos*x - sin*z, z' = sin*x + cos*z for origin and direction.
+RT_D void ray_to_object(const DScene& sc, uint32_t xf, float3& o, float3& d) {
+    float4 rot = sc.xforms[2 * (size_t)xf], off = sc.xforms[2 * (size_t)xf + 1];
+    float s = rot.x, c = rot.y;
+    float3 o1 = o - f3(off);
+    o = f3((c * o1.x) - (s * o1.z), o1.y, (s * o1.x) + (c * o1.z));
+    d = f3((c * d.x) - (s * d.z), d.y, (s * d.x) + (c * d.z));
+}
+// The way back for a hit record (src/math/ray.rs:75-105): rotate point and normal,
+// then add the offset to the point.
+RT_D void hit_to_world(const DScene& sc, uint32_t xf, float3& p, float3& n) {
+    float4 rot = sc.xforms[2 * (size_t)xf], off = sc.xforms[2 * (size_t)xf + 1];
+    float s = rot.x, c = rot.y;
+    p = f3((c * p.x) + (s * p.z), p.y, (-s * p.x) + (c * p.z)) + f3(off);
+    n = f3((c * n.x) + (s * n.z), n.y, (-s * n.x) + (c * n.z));
+}
+
+template <bool COUNT>
+RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float time, float a, float tmin, float tmax, float& t, Probe& pr) {
+    const uint32_t kind = ref_kind(ref), idx = ref_index(ref);
+    if (kind == KIND_SPHERE) {
+        if (COUNT) pr.spheres++;
+        float4 s = sc.spheres[idx];
+        if (ref_placed(ref)) {
+            ray_to_object(sc, sc.sphere_meta[idx].z, o, d);
+            a = dot3(d, d);
+        }
+        return sphere_root(f3(s), s.w, o, d, a, tmin, tmax, t);
+    } else if (kind == KIND_MOVING) {
+        if (COUNT) pr.spheres++;
+        float4 s0 = sc.moving[2 * (size_t)idx], s1 = sc.moving[2 * (size_t)idx + 1];
+        if (ref_placed(ref)) {
+            ray_to_object(sc, sc.moving_meta[idx].z, o, d);
+            a = dot3(d, d);
+        }
+        float3 c = f3(s0) + time * f3(s1);  // MovingSphere::hit, src/hittable.rs:310
+        return sphere_root(c, s0.w, o, d, a, tmin, tmax, t);
+    } else {
+        if (COUNT) pr.quads++;
+        const float4* q4 = sc.quads + 4 * (size_t)idx;
+        if (ref_placed(ref)) ray_to_object(sc, __float_as_uint(q4[3].w), o, d);
+        return quad_root(q4, o, d, tmin, tmax, t);
+    }
+}
+
+// Closest hit of a medium's boundary object inside (lo, hi): the two nested
+// queries of ConstantMediumPhase1/2 (src/math/ray.rs:108-128,250-265).
+template <bool COUNT>
+RT_D bool boundary_root(const DScene& sc, const DMedium& m, float3 o, float3 d, float time, float a, float lo, float hi, float& t,
+                        Probe& pr) {
+    bool any = false;
+    for (uint32_t i = 0; i < m.n_boundary; ++i) {
+        uint32_t ref = sc.boundary_refs[m.first_boundary + i];
+        float tt;
+        if (leaf_root<COUNT>(sc, ref, o, d, time, a, lo, hi, tt, pr)) {
+            any = true;
+            hi = tt;
+        }
+    }
+    t = hi;
+    return any;
+}
+
+struct MediumKey {
+    uint64_t seed;
+    uint32_t pixel, sample, bounce;
+};
+
+// ConstantMediumPhase2 (src/math/ray.rs:131-163): free-path sampling inside
+// [t1, t2] clamped to the current interval.
+template <bool COUNT>
+RT_D bool medium_root(const DScene& sc, uint32_t idx, float3 o, float3 d, float time, float a, float tmin, float tmax,
+                      const MediumKey& key, float& t, Probe& pr) {
+    if (COUNT) pr.media++;
+    DMedium m = sc.media[idx];
+    float t1, t2;
+    if (!boundary_root<COUNT>(sc, m, o, d, time, a, -RT_INF, RT_INF, t1, pr)) return false;
+    if (!boundary_root<COUNT>(sc, m, o, d, time, a, 0.0001f + t1, RT_INF, t2, pr)) return false;
+    if (t1 < tmin) t1 = tmin;
+    if (t2 > tmax) t2 = tmax;
+    if (t1 >= t2) return false;
+    t1 = fmaxf(t1, 0.0f);
+    float ray_len = sqrtf(a);
+    float distance_inside = (t2 - t1) * ray_len;
+    Rng rng;
+    rng.init(path_key(key.seed, key.pixel, key.sample), key.bounce, STREAM_MEDIUM0 + idx);
+    // f32::log(x, E as f32) = ln(x) / ln(2.7182817f) = ln(x) / 0.99999994f
+    float hit_distance = m.neg_inv_density * (logf(rng.next()) / 0.99999994f);
+    if (hit_distance > distance_inside) return false;
+    t = t1 + hit_distance / ray_len;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Closest hit over the flattened BVH.  Returns the leaf reference (REF_NONE on
+// a miss) and its t.  Near child first; the far child's entry distance is kept
+// on the stack so that it can be dropped once a closer hit is known.
+// ---------------------------------------------------------------------------
+template <bool COUNT>
+RT_D uint32_t closest_hit(const DScene& sc, float3 o, float3 d, float time, float tmin, float tmax, const MediumKey& key, float& t_hit,
+                          Probe& pr) {
+    uint32_t best = REF_NONE;
+    uint32_t cur = sc.root;
+    if (cur == REF_NONE) return best;
+    const float a = dot3(d, d);
+    const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t stack_ref[STACK_SIZE];
+    float stack_t[STACK_SIZE];
+    int sp = 0;
+
+    for (;;) {
+        while (!ref_is_leaf(cur)) {
+            if (COUNT) pr.nodes++;
+            const float4* n = sc.nodes + 4 * (size_t)cur;
+            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            bool hl, hr;
+            float l_in, r_in;
+            {
+#pragma clang fp contract(fast)
+            // slab test of both children; NaNs (0 * inf) drop out of fminf/fmaxf
+            float lx0 = (n0.x - o.x) * inv.x, lx1 = (n0.w - o.x) * inv.x;
+            float ly0 = (n0.y - o.y) * inv.y, ly1 = (n1.x - o.y) * inv.y;
+            float lz0 = (n0.z - o.z) * inv.z, lz1 = (n1.y - o.z) * inv.z;
+            float rx0 = (n1.z - o.x) * inv.x, rx1 = (n2.y - o.x) * inv.x;
+            float ry0 = (n1.w - o.y) * inv.y, ry1 = (n2.z - o.y) * inv.y;
+            float rz0 = (n2.x - o.z) * inv.z, rz1 = (n2.w - o.z) * inv.z;
+            l_in = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), tmin));
+            float l_out = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), tmax));
+            r_in = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), tmin));
+            float r_out = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), tmax));
+            // exit distances widened by 2 ulp: conservative against rounding in the products
+            hl = l_in <= l_out * 1.0000002f;
+            hr = r_in <= r_out * 1.0000002f;
+            }
+            uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+            if (hl && hr) {
+                bool left_first = l_in <= r_in;
+                uint32_t far = left_first ? right : left;
+                float far_t = left_first ? r_in : l_in;
+                cur = left_first ? left : right;
+                stack_ref[sp] = far;
+                stack_t[sp] = far_t;
+                ++sp;
+            } else if (hl) {
+                cur = left;
+            } else if (hr) {
+                cur = right;
+            } else {
+                cur = REF_NONE;
+                break;
+            }
+        }
+        if (cur != REF_NONE) {
+            uint32_t kind = ref_kind(cur), idx = ref_index(cur);
+            float t;
+            bool hit;
+            if (kind == KIND_MEDIUM) hit = medium_root<COUNT>(sc, idx, o, d, time, a, tmin, tmax, key, t, pr);
+            else hit = leaf_root<COUNT>(sc, cur, o, d, time, a, tmin, tmax, t, pr);
+            if (hit) {
+                tmax = t;
+                best = cur;
+            }
+        }
+        // pop, skipping subtrees that start beyond the closest hit so far
+        for (;;) {
+            if (sp == 0) {
+                t_hit = tmax;
+                return best;
+            }
+            --sp;
+            cur = stack_ref[sp];
+            if (stack_t[sp] <= tmax) break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Hit geometry: HitRecord fields (src/hittable.rs:7-26) rebuilt from (ray, t, leaf)
+// ---------------------------------------------------------------------------
+struct HitGeom {
+    float3 p, normal;
+    float3 uv_dir;      // sphere: outward normal in object space (input of get_sphere_uv)
+    float u, v;         // quad: alpha, beta; others filled on demand
+    uint32_t material, prim_id;
+    bool front_face;
+    bool uv_ready;
+};
+
+// get_sphere_uv (src/hittable.rs:341-352)
+RT_D void sphere_uv(float3 p, float& u, float& v) {
+    const float PI = 3.14159265358979323846f;
+    float theta = acosf(-p.y);
+    float phi = atan2f(-p.z, p.x) + PI;
+    u = phi / (2.0f * PI);
+    v = theta / PI;
+}
+
+RT_D void set_face_normal(HitGeom& g, float3 d, float3 outward) {  // src/hittable.rs:22-25
+    g.front_face = dot3(d, outward) < 0.0f;
+    g.normal = g.front_face ? outward : -outward;
+}
+
+RT_D HitGeom resolve_hit(const DScene& sc, uint32_t ref, float3 o, float3 d, float time, float t) {
+    HitGeom g;
+    g.u = 0.0f;
+    g.v = 0.0f;
+    g.uv_ready = true;
+    g.uv_dir = f3(0, 0, 0);
+    uint32_t kind = ref_kind(ref), idx = ref_index(ref);
+    if (kind == KIND_MEDIUM) {  // src/math/ray.rs:153-159
+        DMedium m = sc.media[idx];
+        g.p = o + t * d;
+        g.normal = f3(1.0f, 0.0f, 0.0f);
+        g.front_face = true;
+        g.material = m.phase_material;
+        g.prim_id = m.prim_id;
+        return g;
+    }
+    uint32_t xf = 0xFFFFFFFFu;
+    if (kind == KIND_QUAD) {
+        const float4* q4 = sc.quads + 4 * (size_t)idx;
+        float4 nd = q4[0], qq = q4[1], A = q4[2], B = q4[3];
+        if (ref_placed(ref)) {
+            xf = __float_as_uint(B.w);
+            ray_to_object(sc, xf, o, d);
+        }
+        g.p = o + t * d;
+        float3 h = g.p - f3(qq);
+        g.u = dot3(h, f3(A));
+        g.v = dot3(h, f3(B));
+        set_face_normal(g, d, f3(nd));
+        g.material = __float_as_uint(qq.w);
+        g.prim_id = __float_as_uint(A.w);
+    } else {
+        float3 c;
+        float r;
+        uint4 meta;
+        if (kind == KIND_SPHERE) {
+            float4 s = sc.spheres[idx];
+            c = f3(s); r = s.w;
+            meta = sc.sphere_meta[idx];
+        } else {
+            float4 s0 = sc.moving[2 * (size_t)idx], s1 = sc.moving[2 * (size_t)idx + 1];
+            c = f3(s0) + time * f3(s1); r = s0.w;
+            meta = sc.moving_meta[idx];
+        }
+        if (ref_placed(ref)) {
+            xf = meta.z;
+            ray_to_object(sc, xf, o, d);
+        }
+        g.p = o + t * d;
+        float3 outward = (1.0f / r) * (g.p - c);
+        set_face_normal(g, d, outward);
+        g.material = meta.x;
+        g.prim_id = meta.y;
+        g.uv_dir = outward;  // object space, as get_sphere_uv sees it (src/hittable.rs:284)
+        g.uv_ready = false;
+    }
+    if (xf != 0xFFFFFFFFu) hit_to_world(sc, xf, g.p, g.normal);
+    return g;
+}
+
+RT_D void ensure_uv(HitGeom& g) {
+    if (!g.uv_ready) {
+        sphere_uv(g.uv_dir, g.u, g.v);
+        g.uv_ready = true;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// PerlinNoise::noise / turbulance (src/perlin_noise.rs:39-102)
+// ---------------------------------------------------------------------------
+RT_D float perlin_noise(const DPerlin& pn, float3 p) {
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    const uint32_t n = pn.point_count;
+    const uint32_t* px = pn.perm;
+    const uint32_t* py = pn.perm + n;
+    const uint32_t* pz = pn.perm + 2 * n;
+    uint32_t ix[2] = {px[(uint32_t)(i & 255) % n], px[(uint32_t)((i + 1) & 255) % n]};
+    uint32_t iy[2] = {py[(uint32_t)(j & 255) % n], py[(uint32_t)((j + 1) & 255) % n]};
+    uint32_t iz[2] = {pz[(uint32_t)(k & 255) % n], pz[(uint32_t)((k + 1) & 255) % n]};
+    float uu = u * u * (3.0f - 2.0f * u);
+    float vv = v * v * (3.0f - 2.0f * v);
+    float ww = w * w * (3.0f - 2.0f * w);
+    float accum = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float4 g = pn.vecs[(ix[a] ^ iy[b] ^ iz[c]) % n];
+                float3 wv = f3(u - (float)a, v - (float)b, w - (float)c);
+                accum += (a ? uu : 1.0f - uu) * (b ? vv : 1.0f - vv) * (c ? ww : 1.0f - ww) * dot3(f3(g), wv);
+            }
+    return accum;
+}
+
+RT_D float perlin_turbulance(const DPerlin& pn, float3 p, int depth) {
+    float accum = 0.0f, weight = 1.0f;
+    for (int i = 0; i < depth; ++i) {
+        accum += weight * perlin_noise(pn, p);
+        weight *= 0.5f;
+        p = 2.0f * p;
+    }
+    return fabsf(accum);
+}
+
+// Texture::value (src/texture.rs:40-73)
+RT_D float3 texture_value(const DScene& sc, uint32_t tex_id, HitGeom& g) {
+    DTexture t = sc.textures[tex_id];
+    for (int guard = 0; guard < 16 && t.kind == RT_TEX_CHECKER; ++guard) {
+        float sum = floorf(t.scale * g.p.x) + floorf(t.scale * g.p.y) + floorf(t.scale * g.p.z);
+        bool is_even = ((int)sum % 2) == 0;
+        t = sc.textures[is_even ? t.even : t.odd];
+    }
+    if (t.kind == RT_TEX_SOLID) return f3(t.r, t.g, t.b);
+    if (t.kind == RT_TEX_IMAGE) {
+        ensure_uv(g);
+        DImage im = sc.images[t.image];
+        float u = fminf(fmaxf(g.u, 0.0f), 1.0f);
+        float v = 1.0f - fminf(fmaxf(g.v, 0.0f), 1.0f);
+        uint32_t i = (uint32_t)(u * (float)(im.width - 1));
+        uint32_t j = (uint32_t)(v * (float)(im.height - 1));
+        size_t at = (size_t)j * im.width + i;
+        float3 px;
+        if (im.format == RT_IMAGE_RGB8) {
+            uchar4 c = ((const uchar4*)im.texels)[at];
+            px = f3((float)c.x / 255.0f, (float)c.y / 255.0f, (float)c.z / 255.0f);
+        } else {
+            px = f3(((const float4*)im.texels)[at]);
+        }
+        return px * px;
+    }
+    if (t.kind == RT_TEX_NOISE) {
+        float s = 1.0f + sinf(t.scale * g.p.z + 10.0f * perlin_turbulance(sc.perlins[t.perlin], g.p, 7));
+        return f3(s * 0.5f, s * 0.5f, s * 0.5f);
+    }
+    return f3(0, 0, 0);
+}
+
+// Vec3::random_unit (src/math/vec3.rs:57-67)
+RT_D float3 random_unit(Rng& rng) {
+    for (;;) {
+        float a = -1.0f + 2.0f * rng.next();
+        float b = -1.0f + 2.0f * rng.next();
+        float c = -1.0f + 2.0f * rng.next();
+        float3 p = f3(a, b, c);
+        if (dot3(p, p) < 1.0f) return unit3(p);
+    }
+}
+
+// reflectance (src/material.rs:155-160)
+RT_D float schlick(float cosine, float rr) {
+    float r0 = (1.0f - rr) / (1.0f + rr);
+    r0 = r0 * r0;
+    float x = 1.0f - cosine;
+    float x2 = x * x;
+    return r0 + (1.0f - r0) * (x * (x2 * x2));
+}
+
+struct ScatterResult {
+    float3 dir, attenuation, emitted;
+    bool scattered;
+};
+
+// Material::emitted + Material::scatter (src/material.rs:65-122)
+RT_D ScatterResult shade_hit(const DScene& sc, HitGeom& g, float3 d_in, Rng& rng) {
+    ScatterResult r;
+    r.emitted = f3(0, 0, 0);
+    r.attenuation = f3(0, 0, 0);
+    r.dir = f3(0, 0, 0);
+    r.scattered = false;
+    DMaterial m = sc.materials[g.material];
+    switch (m.kind) {
+        case RT_MAT_LAMBERTIAN: {
+            float3 dir = g.normal + random_unit(rng);
+            if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = g.normal;
+            r.dir = dir;
+            r.attenuation = texture_value(sc, m.texture, g);
+            r.scattered = true;
+            break;
+        }
+        case RT_MAT_METAL: {
+            float fuzz = fminf(m.param, 1.0f);
+            float3 ud = unit3(d_in);
+            float3 reflected = ud - (2.0f * dot3(ud, g.normal)) * g.normal;
+            float3 dir = reflected + fuzz * random_unit(rng);
+            if (dot3(dir, g.normal) > 0.0f) {
+                r.dir = dir;
+                r.attenuation = texture_value(sc, m.texture, g);
+                r.scattered = true;
+            }
+            break;
+        }
+        case RT_MAT_DIELECTRIC: {
+            r.attenuation = texture_value(sc, m.texture, g);
+            float ratio = g.front_face ? 1.0f / m.param : m.param;
+            float3 ud = unit3(d_in);
+            float cos_theta = fminf(dot3(-ud, g.normal), 1.0f);
+            float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+            bool cannot_refract = ratio * sin_theta > 1.0f;
+            // the uniform draw happens only when refraction is possible (short-circuit at :97)
+            if (cannot_refract || schlick(cos_theta, ratio) > rng.next()) {
+                r.dir = ud - (2.0f * dot3(ud, g.normal)) * g.normal;
+            } else {  // Vec3::refract, src/math/vec3.rs:89-94
+                float3 perp = ratio * (ud + cos_theta * g.normal);
+                float3 par = (-sqrtf(fabsf(1.0f - dot3(perp, perp)))) * g.normal;
+                r.dir = perp + par;
+            }
+            r.scattered = true;
+            break;
+        }
+        case RT_MAT_ISOTROPIC: {
+            r.dir = random_unit(rng);
+            r.attenuation = texture_value(sc, m.texture, g);
+            r.scattered = true;
+            break;
+        }
+        case RT_MAT_DIFFUSE_LIGHT: {
+            r.emitted = texture_value(sc, m.texture, g);
+            break;
+        }
+        default: break;
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// counters
+// ---------------------------------------------------------------------------
+RT_D unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+RT_D void flush_probe(DCounters* c, const Probe& pr, uint32_t segments, uint32_t hits) {
+    unsigned long long n = wave_sum(pr.nodes), s = wave_sum(pr.spheres), q = wave_sum(pr.quads), m = wave_sum(pr.media);
+    unsigned long long sg = wave_sum(segments), h = wave_sum(hits);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&c->node_visits, n);
+        atomicAdd(&c->sphere_tests, s);
+        atomicAdd(&c->quad_tests, q);
+        atomicAdd(&c->medium_tests, m);
+        atomicAdd(&c->segments, sg);
+        atomicAdd(&c->hits, h);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+
+// get_ray + pixel_sample_square + defocus_disk_sample (src/camera.rs:311-320,368-380).
+// Draw order on the camera stream: jitter x, jitter y, [disk trials], time.
+RT_D void primary_ray(const DCamera& cam, uint64_t seed, uint32_t pixel, uint32_t sample, float3& origin, float3& dir, float& time) {
+    uint32_t x = pixel % cam.width, y = pixel / cam.width;
+    Rng rng;
+    rng.init(path_key(seed, pixel, sample), 0, STREAM_CAMERA);
+    float3 centre = cam.pixel00 + ((float)x * cam.du) + ((float)y * cam.dv);
+    float px = -0.5f + rng.next();
+    float py = -0.5f + rng.next();
+    float3 sample_pt = centre + (px * cam.du + py * cam.dv);
+    origin = cam.centre;
+    if (cam.defocus_angle > 0.0f) {
+        float dx, dy;
+        do {
+            dx = -1.0f + 2.0f * rng.next();
+            dy = -1.0f + 2.0f * rng.next();
+        } while (!(dx * dx + dy * dy < 1.0f));
+        origin = cam.centre + (dx * cam.ddu) + (dy * cam.ddv);
+    }
+    dir = sample_pt - origin;
+    time = rng.next();
+}
+
+// One thread per path of the batch.  Path index = s_local * n_pixels + pixel_local,
+// which is also the initial queue slot.
+__global__ __launch_bounds__(256) void k_raygen(DCamera cam, BatchInfo b, uint64_t seed, float4* __restrict__ ray_o,
+                                                float4* __restrict__ ray_d, float4* __restrict__ thr, uint32_t* __restrict__ counts,
+                                                uint32_t n_counts) {
+    const uint32_t total = b.n_pixels * b.n_samples;
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < n_counts; i += blockDim.x) counts[i] = (i == 0) ? total : 0u;
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        uint32_t s_local = i / b.n_pixels;
+        uint32_t pixel = b.first_pixel + (i - s_local * b.n_pixels);
+        float3 origin, dir;
+        float time;
+        primary_ray(cam, seed, pixel, b.first_sample + s_local, origin, dir, time);
+        ray_o[i] = make_float4(origin.x, origin.y, origin.z, time);
+        ray_d[i] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(i));
+        thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_primary_rays(DCamera cam, uint64_t seed, uint32_t sample, const uint32_t* __restrict__ pixels,
+                                                      unsigned long long n, rt_ray* __restrict__ out) {
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        float3 origin, dir;
+        float time;
+        primary_ray(cam, seed, pixels[i], sample, origin, dir, time);
+        rt_ray r = rt_ray{};
+        r.origin[0] = origin.x; r.origin[1] = origin.y; r.origin[2] = origin.z; r.time = time;
+        r.direction[0] = dir.x; r.direction[1] = dir.y; r.direction[2] = dir.z;
+        r.tmin = 0.001f; r.tmax = RT_INF; r.rng_pixel = pixels[i]; r.rng_sample = sample;
+        out[i] = r;
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce, const uint32_t* __restrict__ counts,
+                                                const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                                uint2* __restrict__ hits, DCounters* counters) {
+    const uint32_t n = counts[bounce];
+    Probe pr;
+    uint32_t segs = 0, nhit = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 ro = ray_o[i], rd = ray_d[i];
+        uint32_t path = __float_as_uint(rd.w);
+        uint32_t s_local = path / b.n_pixels;
+        MediumKey key{seed, b.first_pixel + (path - s_local * b.n_pixels), b.first_sample + s_local, bounce};
+        float t;
+        uint32_t ref = closest_hit<COUNT>(sc, f3(ro), f3(rd), ro.w, 0.001f, RT_INF, key, t, pr);
+        hits[i] = make_uint2(__float_as_uint(t), ref);
+        if (COUNT) { segs++; nhit += (ref != REF_NONE); }
+    }
+    if (COUNT) flush_probe(counters, pr, segs, nhit);
+}
+
+__global__ __launch_bounds__(256) void k_shade(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce, uint32_t* __restrict__ counts,
+                                               const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                               const float4* __restrict__ thr, const uint2* __restrict__ hits,
+                                               float4* __restrict__ out_o, float4* __restrict__ out_d, float4* __restrict__ out_thr,
+                                               float4* __restrict__ radiance) {
+    const uint32_t n = counts[bounce];
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        float4 no, nd, nt;
+        if (i < n) {
+            float4 ro = ray_o[i], rd = ray_d[i], th = thr[i];
+            uint2 h = hits[i];
+            uint32_t path = __float_as_uint(rd.w);
+            float3 T = f3(th);
+            if (h.y == REF_NONE) {  // src/camera.rs:347-349
+                float3 c = T * cam.background;
+                radiance[path] = make_float4(c.x, c.y, c.z, 0.0f);
+            } else {
+                float3 o = f3(ro), d = f3(rd);
+                HitGeom g = resolve_hit(sc, h.y, o, d, ro.w, __uint_as_float(h.x));
+                uint32_t s_local = path / b.n_pixels;
+                Rng rng;
+                rng.init(path_key(seed, b.first_pixel + (path - s_local * b.n_pixels), b.first_sample + s_local), bounce, STREAM_SCATTER);
+                ScatterResult r = shade_hit(sc, g, d, rng);
+                if (!r.scattered) {  // src/camera.rs:354-355
+                    float3 c = T * r.emitted;
+                    radiance[path] = make_float4(c.x, c.y, c.z, 0.0f);
+                } else if (bounce + 1 >= cam.max_depth) {  // depth exhausted, src/camera.rs:342
+                    radiance[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                } else {
+                    float3 nT = T * r.attenuation + r.emitted;  // src/camera.rs:360
+                    alive = true;
+                    no = make_float4(g.p.x, g.p.y, g.p.z, ro.w);
+                    nd = make_float4(r.dir.x, r.dir.y, r.dir.z, rd.w);
+                    nt = make_float4(nT.x, nT.y, nT.z, 0.0f);
+                }
+            }
+        }
+        // queue compaction: one atomic per wave reserves a contiguous run of slots
+        unsigned long long mask = __ballot(alive);
+        if (mask) {
+            uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+            uint32_t slot0 = 0;
+            if (lane == leader) slot0 = atomicAdd(&counts[bounce + 1], (uint32_t)__popcll(mask));
+            slot0 = __shfl(slot0, (int)leader, 64);
+            if (alive) {
+                uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                out_o[slot] = no;
+                out_d[slot] = nd;
+                out_thr[slot] = nt;
+            }
+        }
+    }
+}
+
+// acc[pixel] += colour, one sample after the other (src/camera.rs:295-296)
+__global__ __launch_bounds__(256) void k_accumulate(BatchInfo b, const float4* __restrict__ radiance, float4* __restrict__ acc) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < b.n_pixels; p += gridDim.x * blockDim.x) {
+        float4 a = acc[b.first_pixel + p];
+        for (uint32_t s = 0; s < b.n_samples; ++s) {
+            float4 c = radiance[(size_t)s * b.n_pixels + p];
+            a.x += c.x;
+            a.y += c.y;
+            a.z += c.z;
+        }
+        acc[b.first_pixel + p] = a;
+    }
+}
+
+// Colour::to_rgba (src/math/vec3.rs:252-259)
+RT_D uint32_t to_rgba(float3 c) {
+    float r = sqrtf(c.x) * 255.999f, g = sqrtf(c.y) * 255.999f, bl = sqrtf(c.z) * 255.999f;
+    uint32_t ri = r > 0.0f ? (uint32_t)fminf(r, 4294967040.0f) : 0u;
+    uint32_t gi = g > 0.0f ? (uint32_t)fminf(g, 4294967040.0f) : 0u;
+    uint32_t bi = bl > 0.0f ? (uint32_t)fminf(bl, 4294967040.0f) : 0u;
+    return (ri << 0) | (gi << 8) | (bi << 16);
+}
+
+__global__ __launch_bounds__(256) void k_finalize(const float4* __restrict__ acc, unsigned long long n_pixels, float inv_samples, int mode,
+                                                  float exposure, void* __restrict__ out) {
+    for (unsigned long long p = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; p < n_pixels;
+         p += (unsigned long long)gridDim.x * blockDim.x) {
+        float4 a = acc[p];
+        float3 c = inv_samples * f3(a);
+        if (mode == 0) {
+            ((float4*)out)[p] = make_float4(c.x, c.y, c.z, 0.0f);
+        } else if (mode == 1) {
+            ((float4*)out)[p] = make_float4(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z), 0.0f);
+        } else {
+            float3 m = f3(1.0f - expf(exposure * -c.x), 1.0f - expf(exposure * -c.y), 1.0f - expf(exposure * -c.z));
+            ((uint32_t*)out)[p] = to_rgba(m);
+        }
+    }
+}
+
+// Ray::hit_anything on caller-supplied rays; fills complete hit records.
+__global__ __launch_bounds__(256) void k_intersect(DScene sc, uint64_t seed, const rt_ray* __restrict__ rays, unsigned long long n,
+                                                   rt_hit* __restrict__ out) {
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        rt_ray r = rays[i];
+        float3 o = f3(r.origin[0], r.origin[1], r.origin[2]), d = f3(r.direction[0], r.direction[1], r.direction[2]);
+        MediumKey key{seed, r.rng_pixel, r.rng_sample, r.rng_bounce};
+        Probe pr;
+        float t;
+        uint32_t ref = closest_hit<false>(sc, o, d, r.time, r.tmin, r.tmax, key, t, pr);
+        rt_hit h = rt_hit{};
+        if (ref != REF_NONE) {
+            HitGeom g = resolve_hit(sc, ref, o, d, r.time, t);
+            ensure_uv(g);
+            h.t = t;
+            h.point[0] = g.p.x; h.point[1] = g.p.y; h.point[2] = g.p.z;
+            h.normal[0] = g.normal.x; h.normal[1] = g.normal.y; h.normal[2] = g.normal.z;
+            h.u = g.u; h.v = g.v;
+            h.prim_id = g.prim_id;
+            h.material = g.material;
+            h.front_face = g.front_face ? 1u : 0u;
+            h.hit = 1u;
+        }
+        out[i] = h;
+    }
+}
+
+// Material::emitted/scatter on caller-supplied (ray, hit) pairs: per-material parity checks.
+__global__ __launch_bounds__(256) void k_shade_records(DScene sc, uint64_t seed, const rt_ray* __restrict__ rays,
+                                                       const rt_hit* __restrict__ hits, unsigned long long n,
+                                                       rt_ray* __restrict__ out_rays, float* __restrict__ out_att,
+                                                       float* __restrict__ out_emit) {
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        rt_ray r = rays[i];
+        rt_hit h = hits[i];
+        HitGeom g;
+        g.p = f3(h.point[0], h.point[1], h.point[2]);
+        g.normal = f3(h.normal[0], h.normal[1], h.normal[2]);
+        g.u = h.u; g.v = h.v;
+        g.uv_ready = true;
+        g.uv_dir = f3(0, 0, 0);
+        g.material = h.material;
+        g.prim_id = h.prim_id;
+        g.front_face = h.front_face != 0u;
+        Rng rng;
+        rng.init(path_key(seed, r.rng_pixel, r.rng_sample), r.rng_bounce, STREAM_SCATTER);
+        ScatterResult s = shade_hit(sc, g, f3(r.direction[0], r.direction[1], r.direction[2]), rng);
+        rt_ray o = rt_ray{};
+        if (s.scattered) {
+            o.origin[0] = g.p.x; o.origin[1] = g.p.y; o.origin[2] = g.p.z; o.time = r.time;
+            o.direction[0] = s.dir.x; o.direction[1] = s.dir.y; o.direction[2] = s.dir.z; o.tmin = 1.0f;
+        } else {
+            s.attenuation = f3(0, 0, 0);
+        }
+        out_rays[i] = o;
+        out_att[3 * i] = s.attenuation.x; out_att[3 * i + 1] = s.attenuation.y; out_att[3 * i + 2] = s.attenuation.z;
+        out_emit[3 * i] = s.emitted.x; out_emit[3 * i + 1] = s.emitted.y; out_emit[3 * i + 2] = s.emitted.z;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static inline uint32_t grid_for(unsigned long long n, uint32_t max_blocks) {
+    unsigned long long blocks = (n + 255ull) / 256ull;
+    if (blocks < 1) blocks = 1;
+    if (blocks > max_blocks) blocks = max_blocks;
+    return (uint32_t)blocks;
+}
+
+void launch_raygen(hipStream_t st, uint32_t max_blocks, const DCamera& cam, const BatchInfo& b, uint64_t seed, float4* ray_o, float4* ray_d,
+                   float4* thr, uint32_t* counts, uint32_t n_counts) {
+    uint32_t total = b.n_pixels * b.n_samples;
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(total, max_blocks)), dim3(256), 0, st, cam, b, seed, ray_o, ray_d, thr, counts, n_counts);
+}
+
+void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam, uint64_t seed, uint32_t sample, const uint32_t* pixels,
+                         unsigned long long n, rt_ray* out) {
+    hipLaunchKernelGGL(k_primary_rays, dim3(grid_for(n, max_blocks)), dim3(256), 0, st, cam, seed, sample, pixels, n, out);
+}
+
+void launch_extend(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
+                   uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits, DCounters* counters) {
+    dim3 grid(grid_for(upper_bound, max_blocks));
+    if (counters) hipLaunchKernelGGL(k_extend<true>, grid, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
+    else hipLaunchKernelGGL(k_extend<false>, grid, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
+}
+
+void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const DCamera& cam, const BatchInfo& b,
+                  uint64_t seed, uint32_t bounce, uint32_t* counts, const float4* ray_o, const float4* ray_d, const float4* thr,
+                  const uint2* hits, float4* out_o, float4* out_d, float4* out_thr, float4* radiance) {
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(upper_bound, max_blocks)), dim3(256), 0, st, sc, cam, b, seed, bounce, counts, ray_o, ray_d, thr,
+                       hits, out_o, out_d, out_thr, radiance);
+}
+
+void launch_accumulate(hipStream_t st, uint32_t max_blocks, const BatchInfo& b, const float4* radiance, float4* acc) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(b.n_pixels, max_blocks)), dim3(256), 0, st, b, radiance, acc);
+}
+
+void launch_finalize(hipStream_t st, uint32_t max_blocks, const float4* acc, unsigned long long n_pixels, float inv_samples, int mode,
+                     float exposure, void* out) {
+    hipLaunchKernelGGL(k_finalize, dim3(grid_for(n_pixels, max_blocks)), dim3(256), 0, st, acc, n_pixels, inv_samples, mode, exposure, out);
+}
+
+void launch_intersect(hipStream_t st, uint32_t max_blocks, const DScene& sc, uint64_t seed, const rt_ray* rays, unsigned long long n,
+                      rt_hit* out) {
+    hipLaunchKernelGGL(k_intersect, dim3(grid_for(n, max_blocks)), dim3(256), 0, st, sc, seed, rays, n, out);
+}
+
+void launch_shade_records(hipStream_t st, uint32_t max_blocks, const DScene& sc, uint64_t seed, const rt_ray* rays,
+                          const rt_hit* hits, unsigned long long n, rt_ray* out_rays, float* out_att, float* out_emit) {
+    hipLaunchKernelGGL(k_shade_records, dim3(grid_for(n, max_blocks)), dim3(256), 0, st, sc, seed, rays, hits, n, out_rays, out_att, out_emit);
+}
+
+}  // namespace rt
