@@ -186,26 +186,42 @@ void vec_to_world(const Xf& x, const float in[3], double out[3]) {
     rot_inv(x, v, out);
 }
 
+// Leaf boxes.  For leaves that sit in world space the box is the reference's own AABB,
+// computed in f32 in the reference's order (src/hittable.rs:158-178, src/math/aabb.rs:22-98),
+// because the reference's BVH decides with exactly this box whether a leaf is tested at all.
 struct Aabb {
-    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool empty() const { return mn[0] == INFINITY && mx[0] == -INFINITY; }
+    // AABB::pad_to_minimums (src/math/aabb.rs:79-98)
+    void pad_to_minimums() {
+        const float delta = 0.0001f, delta_half = delta * 0.5f;
+        for (int a = 0; a < 3; ++a)
+            if (std::fabs(mx[a] - mn[a]) < delta) { mn[a] = mn[a] - delta_half; mx[a] = mx[a] + delta_half; }
+    }
+    // AABB::from_points (src/math/aabb.rs:52-58)
+    static Aabb from_points(const float a[3], const float b[3]) {
+        Aabb r;
+        for (int i = 0; i < 3; ++i) { r.mn[i] = a[i] <= b[i] ? a[i] : b[i]; r.mx[i] = a[i] <= b[i] ? b[i] : a[i]; }
+        r.pad_to_minimums();
+        return r;
+    }
+    // AABB::from_aabbs (src/math/aabb.rs:61-69)
+    static Aabb from_aabbs(const Aabb& x, const Aabb& y) {
+        if (y.empty()) return x;
+        Aabb r;
+        for (int i = 0; i < 3; ++i) { r.mn[i] = std::fmin(x.mn[i], y.mn[i]); r.mx[i] = std::fmax(x.mx[i], y.mx[i]); }
+        r.pad_to_minimums();
+        return r;
+    }
+    // conservative growth for placed leaves (world-space bound of an object-space leaf)
     void grow(const double p[3], double r = 0.0) {
         for (int a = 0; a < 3; ++a) {
-            mn[a] = std::min(mn[a], std::nextafter((float)(p[a] - r), -FLT_MAX));
-            mx[a] = std::max(mx[a], std::nextafter((float)(p[a] + r), FLT_MAX));
+            mn[a] = std::min(mn[a], std::nextafter((float)(p[a] - r), -INFINITY));
+            mx[a] = std::max(mx[a], std::nextafter((float)(p[a] + r), INFINITY));
         }
     }
     void grow(const Aabb& o) {
         for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], o.mn[a]); mx[a] = std::max(mx[a], o.mx[a]); }
-    }
-    // Keeps flat boxes (axis-aligned quads) from having zero thickness, as
-    // AABB::pad_to_minimums does (src/math/aabb.rs:79-98), scaled to the coordinates.
-    void pad() {
-        for (int a = 0; a < 3; ++a) {
-            float m = std::max(std::fabs(mn[a]), std::fabs(mx[a]));
-            float eps = std::max(5e-5f, m * 1e-6f);
-            mn[a] -= eps;
-            mx[a] += eps;
-        }
     }
 };
 
@@ -507,8 +523,13 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         point_to_world(xf_of(s.transform), s.centre, c);
         spheres[i] = make_float4(s.centre[0], s.centre[1], s.centre[2], s.radius);
         sphere_meta[i] = make_uint4(s.material, s.prim_id, s.transform, 0);
-        sphere_box[i].grow(c, std::fabs((double)s.radius));
-        sphere_box[i].pad();
+        if (s.transform == RT_NO_TRANSFORM) {
+            float lo[3] = {s.centre[0] - s.radius, s.centre[1] - s.radius, s.centre[2] - s.radius};
+            float hi[3] = {s.centre[0] + s.radius, s.centre[1] + s.radius, s.centre[2] + s.radius};
+            sphere_box[i] = Aabb::from_points(lo, hi);
+        } else {
+            sphere_box[i].grow(c, std::fabs((double)s.radius));
+        }
     }
     for (uint32_t i = 0; i < desc->n_moving_spheres; ++i) {
         const rt_moving_sphere& s = desc->moving_spheres[i];
@@ -519,10 +540,18 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         moving[2 * (size_t)i + 1] = make_float4(s.dcentre[0], s.dcentre[1], s.dcentre[2], 0.0f);
         moving_meta[i] = make_uint4(s.material, s.prim_id, s.transform, 0);
         // union of the boxes at time 0 and 1 (src/hittable.rs:166-171)
-        double p1[3] = {c0[0] + dc[0], c0[1] + dc[1], c0[2] + dc[2]};
-        moving_box[i].grow(c0, std::fabs((double)s.radius));
-        moving_box[i].grow(p1, std::fabs((double)s.radius));
-        moving_box[i].pad();
+        if (s.transform == RT_NO_TRANSFORM) {
+            float r = s.radius, lo[3], hi[3], lo1[3], hi1[3];
+            for (int a = 0; a < 3; ++a) {
+                float at0 = s.centre0[a] + 0.0f * s.dcentre[a], at1 = s.centre0[a] + 1.0f * s.dcentre[a];  // centre.at(0), centre.at(1)
+                lo[a] = at0 - r; hi[a] = at0 + r; lo1[a] = at1 - r; hi1[a] = at1 + r;
+            }
+            moving_box[i] = Aabb::from_aabbs(Aabb::from_points(lo, hi), Aabb::from_points(lo1, hi1));
+        } else {
+            double p1[3] = {c0[0] + dc[0], c0[1] + dc[1], c0[2] + dc[2]};
+            moving_box[i].grow(c0, std::fabs((double)s.radius));
+            moving_box[i].grow(p1, std::fabs((double)s.radius));
+        }
     }
     for (uint32_t i = 0; i < desc->n_quads; ++i) {
         const rt_quad& qd = desc->quads[i];
@@ -554,10 +583,15 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         o[2] = make_float4(A[0], A[1], A[2], __builtin_bit_cast(float, qd.prim_id));
         o[3] = make_float4(B[0], B[1], B[2], __builtin_bit_cast(float, qd.transform));
         quad_meta[i] = make_uint4(qd.material, qd.prim_id, qd.transform, 0);
-        double corner[4][3];
-        for (int a = 0; a < 3; ++a) { corner[0][a] = q[a]; corner[1][a] = q[a] + u[a]; corner[2][a] = q[a] + v[a]; corner[3][a] = q[a] + u[a] + v[a]; }
-        for (auto& cpt : corner) quad_box[i].grow(cpt);
-        quad_box[i].pad();
+        if (qd.transform == RT_NO_TRANSFORM) {
+            float quv[3], qu[3], qv[3];
+            for (int a = 0; a < 3; ++a) { qu[a] = qf[a] + uf[a]; qv[a] = qf[a] + vf[a]; quv[a] = qu[a] + vf[a]; }
+            quad_box[i] = Aabb::from_aabbs(Aabb::from_points(qf, quv), Aabb::from_points(qu, qv));
+        } else {
+            double corner[4][3];
+            for (int a = 0; a < 3; ++a) { corner[0][a] = q[a]; corner[1][a] = q[a] + u[a]; corner[2][a] = q[a] + v[a]; corner[3][a] = q[a] + u[a] + v[a]; }
+            for (auto& cpt : corner) quad_box[i].grow(cpt);
+        }
     }
     auto box_of = [&](const rt_prim_ref& r) -> const Aabb& {
         switch (r.kind) {
@@ -590,6 +624,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         const Aabb& b = box_of(desc->world[i]);
         for (int a = 0; a < 3; ++a) { prims[i].bmin[a] = b.mn[a]; prims[i].bmax[a] = b.mx[a]; }
         prims[i].ref = make_leaf(desc->world[i].kind, desc->world[i].index, placed(desc->world[i]));
+        prims[i].exact = (desc->world[i].kind != RT_PRIM_MEDIUM && !placed(desc->world[i])) ? 1u : 0u;
         for (int a = 0; a < 3; ++a)
             if (!(b.mn[a] <= b.mx[a]) || !std::isfinite(b.mn[a]) || !std::isfinite(b.mx[a]))
                 return fail(RT_ERR_INVALID_ARGUMENT, "world[%u] has a non-finite or empty bounding box", i);

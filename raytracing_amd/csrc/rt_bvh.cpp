@@ -106,7 +106,18 @@ struct Builder {
         return mid;
     }
 
-    void write_child(uint32_t node, int side, const Box& bx, uint32_t ref) {
+    // Boxes of inner nodes and of conservative leaves are widened so that rounding in the
+    // slab test can never cull a box the exact ray touches; exact leaves keep the box the
+    // reference itself would test (AABB::pad_to_minimums already applied by the caller).
+    void write_child(uint32_t node, int side, Box bx, uint32_t ref, bool widen) {
+        if (widen) {
+            for (int a = 0; a < 3; ++a) {
+                float m = std::max(std::fabs(bx.mn[a]), std::fabs(bx.mx[a]));
+                float eps = std::max(5e-5f, m * 1e-6f);
+                bx.mn[a] -= eps;
+                bx.mx[a] += eps;
+            }
+        }
         float* n = nodes + 16 * (size_t)node;
         if (side == 0) {
             n[0] = bx.mn[0]; n[1] = bx.mn[1]; n[2] = bx.mn[2]; n[3] = bx.mx[0]; n[4] = bx.mx[1]; n[5] = bx.mx[2];
@@ -130,10 +141,10 @@ struct Builder {
             size_t cnt = re[side] - rb[side];
             Box bx = bounds(rb[side], re[side]);
             if (cnt == 1) {
-                write_child(node, side, bx, prims[rb[side]].ref);
+                write_child(node, side, bx, prims[rb[side]].ref, prims[rb[side]].exact == 0);
             } else {
                 uint32_t child = next_node.fetch_add(1);
-                write_child(node, side, bx, child);
+                write_child(node, side, bx, child, true);
                 if (deferred && cnt <= spawn_above) deferred->push_back(Task{rb[side], re[side], child, depth + 1});
                 else build_node(child, rb[side], re[side], depth + 1, spawn_above, deferred);
             }

@@ -10,7 +10,8 @@ namespace rt {
 
 struct BuildPrim {
     float bmin[3], bmax[3];
-    uint32_t ref;  // leaf reference stored in the tree
+    uint32_t ref;     // leaf reference stored in the tree
+    uint32_t exact;   // 1: store the box as given (the reference's own leaf AABB); 0: widen it a little
 };
 
 // 16 floats per node, layout documented in rt_device.h.

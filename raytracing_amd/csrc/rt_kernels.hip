@@ -139,6 +139,9 @@ RT_D bool boundary_root(const DScene& sc, const DMedium& m, float3 o, float3 d, 
     return any;
 }
 
+// leaf in world space that is not a medium: top four bits 1kk0 with kk != 11
+RT_D bool exact_leaf_box(uint32_t ref) { return ((ref >> 28) & 9u) == 8u && (ref >> 29) != 7u; }
+
 struct MediumKey {
     uint64_t seed;
     uint32_t pixel, sample, bounce;
@@ -192,7 +195,7 @@ RT_D uint32_t closest_hit(const DScene& sc, float3 o, float3 d, float time, floa
             const float4* n = sc.nodes + 4 * (size_t)cur;
             float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
             bool hl, hr;
-            float l_in, r_in;
+            float l_in, r_in, l_out, r_out;
             {
 #pragma clang fp contract(fast)
             // slab test of both children; NaNs (0 * inf) drop out of fminf/fmaxf
@@ -203,14 +206,17 @@ RT_D uint32_t closest_hit(const DScene& sc, float3 o, float3 d, float time, floa
             float ry0 = (n1.w - o.y) * inv.y, ry1 = (n2.z - o.y) * inv.y;
             float rz0 = (n2.x - o.z) * inv.z, rz1 = (n2.w - o.z) * inv.z;
             l_in = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), tmin));
-            float l_out = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), tmax));
+            l_out = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), tmax));
             r_in = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), tmin));
-            float r_out = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), tmax));
-            // exit distances widened by 2 ulp: conservative against rounding in the products
-            hl = l_in <= l_out * 1.0000002f;
-            hr = r_in <= r_out * 1.0000002f;
+            r_out = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), tmax));
             }
             uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+            // Inner boxes (and the world-space bounds of placed leaves and media) are conservative:
+            // their exit distance is widened by 2 ulp.  The box of a leaf that sits in world space
+            // is the reference's own AABB and is tested exactly as AABBx2::hit does
+            // (src/math/aabb.rs:127-167), so the same leaves get tested as in the reference.
+            hl = l_in <= l_out * (exact_leaf_box(left) ? 1.0f : 1.0000002f);
+            hr = r_in <= r_out * (exact_leaf_box(right) ? 1.0f : 1.0000002f);
             if (hl && hr) {
                 bool left_first = l_in <= r_in;
                 uint32_t far = left_first ? right : left;

@@ -1,0 +1,33 @@
+"""Multi-GPU partitioning of a render: sample slicing + one sum-reduce.
+
+Every (pixel, sample) is independent (the random numbers are a pure function of
+them), so a render of S samples on N ranks is: rank r renders the contiguous
+sample numbers of `sample_slice(S, r, N)` for ALL pixels into its own W x H x 4
+accumulation buffer, then one all-reduce / reduce (sum, f32) over RCCL combines
+the buffers.  There is no other exchange step.  The helpers below are pure
+functions plus one collective call, so they can be exercised on CPU with gloo.
+"""
+
+
+def sample_slice(total_samples, rank, world_size, first_sample=1):
+    """(first_sample_number, count) of this rank's share; shares differ by at most one
+    sample and cover [first_sample, first_sample + total_samples) without overlap."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    base, extra = divmod(total_samples, world_size)
+    count = base + (1 if rank < extra else 0)
+    start = first_sample + rank * base + min(rank, extra)
+    return start, count
+
+
+def reduce_accumulators(acc, dst=None, group=None):
+    """Sum the per-rank accumulation buffers (a torch tensor) in place: to every rank
+    (dst=None, all-reduce) or to rank `dst` only."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return acc
+    if dst is None:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    else:
+        dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return acc
