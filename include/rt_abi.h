@@ -357,10 +357,12 @@ int rt_primary_rays(rt_ctx* ctx, const rt_camera_desc* cam, uint64_t seed,
 /* Block until all work enqueued by this context has finished. */
 int rt_ctx_synchronize(rt_ctx* ctx);
 
-/* Timing of the most recent rt_render_accumulate*_ call measured with HIP
- * events on the context's stream: total and per-phase milliseconds, launches
- * per phase.  Valid after rt_ctx_synchronize.  phase: 0 raygen, 1 extend,
- * 2 shade, 3 accumulate. */
+/* Timing with HIP events on the context's stream.  rt_ctx_last_render_ms: the
+ * most recent rt_render_accumulate* call, first to last launch.  With phase
+ * timing on, every kernel launch is bracketed by an event pair;
+ * rt_ctx_synchronize sums them per phase over all renders enqueued since the
+ * previous rt_ctx_synchronize, and rt_ctx_phase_ms reads the sums (milliseconds,
+ * number of launches).  phase: 0 raygen, 1 extend, 2 shade, 3 accumulate. */
 int rt_ctx_last_render_ms(rt_ctx* ctx, float* total_ms);
 int rt_ctx_set_phase_timing(rt_ctx* ctx, int enabled);
 int rt_ctx_phase_ms(rt_ctx* ctx, int phase, float* ms, uint32_t* launches);

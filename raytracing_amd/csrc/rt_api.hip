@@ -1,6 +1,6 @@
 // rt_api.hip — implementation of the C ABI declared in include/rt_abi.h:
-// context / scene lifetime, scene ingestion (validation, baking of Move/RotateY
-// placements, BVH build, upload) and the host side of the wavefront loop.
+// context / scene lifetime, scene ingestion (validation, leaf boxes,
+// BVH build, upload) and the host side of the wavefront loop.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -732,7 +732,6 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
     if (chunk_pixels == npix) spb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->batch_paths / npix, n_samples));
     const uint32_t n_counts = cam->max_depth + 2;
     if ((e = ensure_queues(c, (uint64_t)chunk_pixels * spb, n_counts))) return e;
-    if ((e = collect_phases(c))) return e;
     DCamera dcam = to_dcamera(cam);
     DCounters* counters = c->counters_on ? c->d_counters : nullptr;
 
@@ -767,7 +766,7 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
     HIP_TRY(hipEventRecord(c->ev_end, c->stream));
     HIP_TRY(hipGetLastError());
     c->have_render_time = true;
-    c->phase_pending = c->phase_timing;
+    c->phase_pending = c->phase_pending || c->phase_timing;
     if (c->counters_on) {
         // paths started: one per (pixel, sample)
         unsigned long long add = npix * n_samples;

@@ -2,7 +2,7 @@
 // reference crate `raytracing-improved` (Camera, Hittable/BVH, Material, Texture,
 // PerlinNoise, Seed, World) so that scene code reads like the reference's
 // src/main.rs.  Nothing here traces rays: Camera::{empty,realtime,hdr}_render
-// flatten the scene once (flatten.cpp) and call the C ABI of include/rt_abi.h,
+// flatten the scene once (raytracing.cpp) and call the C ABI of include/rt_abi.h,
 // which runs the render loop on the GPU.
 #pragma once
 
