@@ -65,6 +65,7 @@ struct rt_ctx {
     float4* ray_d[2] = {nullptr, nullptr};
     float4* thr[2] = {nullptr, nullptr};
     uint2* hits = nullptr;
+    uint32_t* tex_list = nullptr;
     float4* radiance = nullptr;
     uint32_t* counts = nullptr;
     uint32_t counts_cap = 0;
@@ -84,6 +85,7 @@ struct rt_scene {
     std::vector<void*> allocations;
     DScene d{};
     uint32_t bvh_depth = 0;
+    bool has_textures = false;  // some material's texture is not a plain colour
 };
 
 namespace {
@@ -101,8 +103,10 @@ void free_queues(rt_ctx* c) {
         c->ray_o[i] = c->ray_d[i] = c->thr[i] = nullptr;
     }
     if (c->hits) (void)hipFree(c->hits);
+    if (c->tex_list) (void)hipFree(c->tex_list);
     if (c->radiance) (void)hipFree(c->radiance);
     c->hits = nullptr;
+    c->tex_list = nullptr;
     c->radiance = nullptr;
     c->queue_cap = 0;
 }
@@ -116,6 +120,7 @@ int ensure_queues(rt_ctx* c, uint64_t paths, uint32_t n_counts) {
             HIP_TRY(hipMalloc((void**)&c->thr[i], paths * sizeof(float4)));
         }
         HIP_TRY(hipMalloc((void**)&c->hits, paths * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void**)&c->tex_list, paths * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&c->radiance, paths * sizeof(float4)));
         c->queue_cap = paths;
     }
@@ -515,14 +520,32 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
 
     // bake placements into world-space primitives
     std::vector<float4> spheres(desc->n_spheres), moving(2 * (size_t)desc->n_moving_spheres), quads(4 * (size_t)desc->n_quads);
-    std::vector<uint4> sphere_meta(desc->n_spheres), moving_meta(desc->n_moving_spheres), quad_meta(desc->n_quads);
+    std::vector<uint4> sphere_meta(2 * (size_t)desc->n_spheres), moving_meta(2 * (size_t)desc->n_moving_spheres),
+        quad_meta(2 * (size_t)desc->n_quads), medium_meta(2 * (size_t)desc->n_media);
+    // shading record of a leaf: see the layout notes in rt_device.h
+    auto fill_meta = [&](uint4* m, uint32_t material, uint32_t prim_id, uint32_t transform) {
+        const rt_material& mat = desc->materials[material];
+        const rt_texture& tex = desc->textures[mat.texture];
+        uint32_t cls;
+        if (tex.kind != RT_TEX_SOLID) cls = CLS_TEXTURED;
+        else switch (mat.kind) {
+            case RT_MAT_DIFFUSE_LIGHT: cls = CLS_LIGHT; break;
+            case RT_MAT_LAMBERTIAN: cls = CLS_LAMBERTIAN; break;
+            case RT_MAT_METAL: cls = CLS_METAL; break;
+            case RT_MAT_DIELECTRIC: cls = CLS_DIELECTRIC; break;
+            default: cls = CLS_ISOTROPIC; break;
+        }
+        m[0] = make_uint4(material, prim_id, transform, cls | (mat.kind << 8) | (tex.kind << 16));
+        m[1] = make_uint4(__builtin_bit_cast(uint32_t, mat.param), __builtin_bit_cast(uint32_t, tex.colour[0]),
+                          __builtin_bit_cast(uint32_t, tex.colour[1]), __builtin_bit_cast(uint32_t, tex.colour[2]));
+    };
     std::vector<Aabb> sphere_box(desc->n_spheres), moving_box(desc->n_moving_spheres), quad_box(desc->n_quads), medium_box(desc->n_media);
     for (uint32_t i = 0; i < desc->n_spheres; ++i) {
         const rt_sphere& s = desc->spheres[i];
         double c[3];
         point_to_world(xf_of(s.transform), s.centre, c);
         spheres[i] = make_float4(s.centre[0], s.centre[1], s.centre[2], s.radius);
-        sphere_meta[i] = make_uint4(s.material, s.prim_id, s.transform, 0);
+        fill_meta(&sphere_meta[2 * (size_t)i], s.material, s.prim_id, s.transform);
         if (s.transform == RT_NO_TRANSFORM) {
             float lo[3] = {s.centre[0] - s.radius, s.centre[1] - s.radius, s.centre[2] - s.radius};
             float hi[3] = {s.centre[0] + s.radius, s.centre[1] + s.radius, s.centre[2] + s.radius};
@@ -538,7 +561,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         vec_to_world(xf_of(s.transform), s.dcentre, dc);
         moving[2 * (size_t)i] = make_float4(s.centre0[0], s.centre0[1], s.centre0[2], s.radius);
         moving[2 * (size_t)i + 1] = make_float4(s.dcentre[0], s.dcentre[1], s.dcentre[2], 0.0f);
-        moving_meta[i] = make_uint4(s.material, s.prim_id, s.transform, 0);
+        fill_meta(&moving_meta[2 * (size_t)i], s.material, s.prim_id, s.transform);
         // union of the boxes at time 0 and 1 (src/hittable.rs:166-171)
         if (s.transform == RT_NO_TRANSFORM) {
             float r = s.radius, lo[3], hi[3], lo1[3], hi1[3];
@@ -582,7 +605,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         o[1] = make_float4(qf[0], qf[1], qf[2], __builtin_bit_cast(float, qd.material));
         o[2] = make_float4(A[0], A[1], A[2], __builtin_bit_cast(float, qd.prim_id));
         o[3] = make_float4(B[0], B[1], B[2], __builtin_bit_cast(float, qd.transform));
-        quad_meta[i] = make_uint4(qd.material, qd.prim_id, qd.transform, 0);
+        fill_meta(&quad_meta[2 * (size_t)i], qd.material, qd.prim_id, qd.transform);
         if (qd.transform == RT_NO_TRANSFORM) {
             float quv[3], qu[3], qv[3];
             for (int a = 0; a < 3; ++a) { qu[a] = qf[a] + uf[a]; qv[a] = qf[a] + vf[a]; quv[a] = qu[a] + vf[a]; }
@@ -615,22 +638,65 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     for (uint32_t i = 0; i < desc->n_media; ++i) {
         const rt_medium& m = desc->media[i];
         media[i] = DMedium{m.first_boundary, m.n_boundary, m.neg_inv_density, m.phase_material, m.prim_id, {0, 0, 0}};
+        fill_meta(&medium_meta[2 * (size_t)i], m.phase_material, m.prim_id, RT_NO_TRANSFORM);
         for (uint32_t k = 0; k < m.n_boundary; ++k) medium_box[i].grow(box_of(desc->boundary[m.first_boundary + k]));
     }
 
-    // flattened BVH over the world leaves
-    std::vector<BuildPrim> prims(desc->n_world);
+    // flattened BVH over the world leaves; leaves that span most of the scene (a ground sphere,
+    // a scene-wide fog) would sit at the top of any tree, so they are tested up front instead
+    std::vector<BuildPrim> prims;
+    prims.reserve(desc->n_world);
+    Aabb whole;
     for (uint32_t i = 0; i < desc->n_world; ++i) {
         const Aabb& b = box_of(desc->world[i]);
-        for (int a = 0; a < 3; ++a) { prims[i].bmin[a] = b.mn[a]; prims[i].bmax[a] = b.mx[a]; }
-        prims[i].ref = make_leaf(desc->world[i].kind, desc->world[i].index, placed(desc->world[i]));
-        prims[i].exact = (desc->world[i].kind != RT_PRIM_MEDIUM && !placed(desc->world[i])) ? 1u : 0u;
         for (int a = 0; a < 3; ++a)
             if (!(b.mn[a] <= b.mx[a]) || !std::isfinite(b.mn[a]) || !std::isfinite(b.mx[a]))
                 return fail(RT_ERR_INVALID_ARGUMENT, "world[%u] has a non-finite or empty bounding box", i);
+        whole.grow(b);
+    }
+    auto half_area = [](const Aabb& b) {
+        double dx = (double)b.mx[0] - b.mn[0], dy = (double)b.mx[1] - b.mn[1], dz = (double)b.mx[2] - b.mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    uint32_t n_global = 0, global_refs[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = 0; i < desc->n_world; ++i) {
+        const rt_prim_ref& w = desc->world[i];
+        const Aabb& b = box_of(w);
+        uint32_t ref = make_leaf(w.kind, w.index, placed(w));
+        bool eligible = (w.kind == RT_PRIM_MEDIUM || (w.kind == RT_PRIM_SPHERE && !placed(w))) && desc->n_world > 4;
+        if (eligible && n_global < 7 && half_area(b) >= 0.25 * half_area(whole)) {
+            global_refs[n_global++] = ref;
+            continue;
+        }
+        BuildPrim bp;
+        for (int a = 0; a < 3; ++a) { bp.bmin[a] = b.mn[a]; bp.bmax[a] = b.mx[a]; }
+        bp.ref = ref;
+        bp.exact = (w.kind != RT_PRIM_MEDIUM && !placed(w)) ? 1u : 0u;
+        prims.push_back(bp);
     }
     FlatBvh bvh = build_bvh(prims, 0);
     if (bvh.max_depth > 62) return fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.max_depth);
+    {   // every reference the kernels will follow must point inside its array
+        auto ref_ok = [&](uint32_t r) {
+            if (!ref_is_leaf(r)) return r < bvh.n_nodes;
+            uint32_t idx = ref_index(r);
+            switch (ref_kind(r)) {
+                case KIND_SPHERE: return idx < desc->n_spheres;
+                case KIND_MOVING: return idx < desc->n_moving_spheres;
+                case KIND_QUAD: return idx < desc->n_quads;
+                default: return idx < desc->n_media && !ref_placed(r);
+            }
+        };
+        bool ok = bvh.root == REF_NONE || ref_ok(bvh.root);
+        for (uint32_t i = 0; ok && i < bvh.n_nodes; ++i) {
+            uint32_t l, r;
+            std::memcpy(&l, &bvh.nodes[16 * (size_t)i + 12], 4);
+            std::memcpy(&r, &bvh.nodes[16 * (size_t)i + 13], 4);
+            ok = ref_ok(l) && ref_ok(r);
+        }
+        for (uint32_t i = 0; ok && i < n_global; ++i) ok = ref_ok(global_refs[i]);
+        if (!ok) return fail(RT_ERR_HIP, "internal error: the flattened BVH holds an invalid reference");
+    }
 
     std::vector<DMaterial> materials(desc->n_materials);
     for (uint32_t i = 0; i < desc->n_materials; ++i) materials[i] = DMaterial{desc->materials[i].kind, desc->materials[i].param, desc->materials[i].texture, 0};
@@ -655,6 +721,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     if ((e = upload(sc, quads, &sc->d.quads))) return bail(e);
     if ((e = upload(sc, quad_meta, &sc->d.quad_meta))) return bail(e);
     if ((e = upload(sc, media, &sc->d.media))) return bail(e);
+    if ((e = upload(sc, medium_meta, &sc->d.medium_meta))) return bail(e);
     if ((e = upload(sc, boundary_refs, &sc->d.boundary_refs))) return bail(e);
     if ((e = upload(sc, xforms, &sc->d.xforms))) return bail(e);
     if ((e = upload(sc, materials, &sc->d.materials))) return bail(e);
@@ -705,6 +772,10 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     sc->d.n_nodes = bvh.n_nodes;
     sc->d.n_media = desc->n_media;
     sc->d.n_materials = desc->n_materials;
+    for (uint32_t i = 0; i < desc->n_materials; ++i)
+        if (desc->textures[desc->materials[i].texture].kind != RT_TEX_SOLID) sc->has_textures = true;
+    sc->d.n_global = n_global;
+    for (int i = 0; i < 7; ++i) sc->d.global_refs[i] = global_refs[i];
     *out = sc;
     return RT_OK;
 }
@@ -730,7 +801,9 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
     const uint32_t chunk_pixels = (uint32_t)std::min<uint64_t>(npix, c->batch_paths);
     uint32_t spb = 1;  // samples per batch
     if (chunk_pixels == npix) spb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->batch_paths / npix, n_samples));
-    const uint32_t n_counts = cam->max_depth + 2;
+    // counts[0 .. max_depth + 1]: queue lengths per bounce; counts[max_depth + 2 + bounce]: textured hits of that bounce
+    const uint32_t n_queue_counts = cam->max_depth + 2;
+    const uint32_t n_counts = 2 * cam->max_depth + 2;
     if ((e = ensure_queues(c, (uint64_t)chunk_pixels * spb, n_counts))) return e;
     DCamera dcam = to_dcamera(cam);
     DCounters* counters = c->counters_on ? c->d_counters : nullptr;
@@ -752,8 +825,9 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
                 launch_extend(c->stream, c->max_blocks, total, sc->d, b, seed, bounce, c->counts, c->ray_o[cur], c->ray_d[cur], c->hits, counters);
                 if ((e = phase_end(c, ep))) return e;
                 if ((e = phase_begin(c, 2, &ep))) return e;
-                launch_shade(c->stream, c->max_blocks, total, sc->d, dcam, b, seed, bounce, c->counts, c->ray_o[cur], c->ray_d[cur],
-                             c->thr[cur], c->hits, c->ray_o[cur ^ 1], c->ray_d[cur ^ 1], c->thr[cur ^ 1], c->radiance);
+                launch_shade(c->stream, c->max_blocks, total, sc->d, dcam, b, seed, bounce, c->counts, c->counts + n_queue_counts + bounce,
+                             c->tex_list, c->ray_o[cur], c->ray_d[cur], c->thr[cur], c->hits, c->ray_o[cur ^ 1], c->ray_d[cur ^ 1],
+                             c->thr[cur ^ 1], c->radiance, sc->has_textures);
                 if ((e = phase_end(c, ep))) return e;
                 cur ^= 1;
             }

@@ -159,14 +159,12 @@ FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads) {
     const size_t n = prims.size();
     if (n == 0) return out;
     if (n == 1) {
-        // one node whose right slot is empty (inverted box never passes the slab test)
-        out.nodes.assign(16, 0.0f);
-        float* nd = out.nodes.data();
-        for (int a = 0; a < 3; ++a) { nd[a] = prims[0].bmin[a]; nd[3 + a] = prims[0].bmax[a]; nd[6 + a] = FLT_MAX; nd[9 + a] = -FLT_MAX; }
-        uint32_t none = 0xFFFFFFFFu;
-        std::memcpy(&nd[12], &prims[0].ref, 4);
-        std::memcpy(&nd[13], &none, 4);
-        out.root = 0; out.n_nodes = 1; out.max_depth = 1;
+        // no inner node at all: the root reference is the leaf itself.  (The reference's one-leaf
+        // BVH node holds the leaf twice, the second time with an empty box, and an empty box
+        // passes its min/max slab test, so the leaf is tested whatever the ray: same thing.)
+        out.root = prims[0].ref;
+        out.n_nodes = 0;
+        out.max_depth = 0;
         return out;
     }
     out.nodes.assign(16 * (n - 1), 0.0f);

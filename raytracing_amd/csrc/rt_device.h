@@ -39,7 +39,10 @@ RT_HD bool ref_placed(uint32_t r) { return (r & REF_PLACED) != 0; }
 //                       A.xyz, bits(prim_id) | B.xyz, bits(transform)  (64 B)
 //           N = unit(u x v), D = N.q, w = n/(n.n), A = v x w, B = w x u so that
 //           alpha = (p-q).A and beta = (p-q).B (src/hittable.rs:372-408)
-//   *_meta  uint4: material, prim_id, transform (or RT_NO_TRANSFORM), 0
+//   *_meta  2 x uint4 per leaf (spheres, moving spheres, quads, media): what shading needs in
+//           one 32-byte read: material, prim_id, transform (or RT_NO_TRANSFORM),
+//           class | material kind << 8 | texture kind << 16  ||  bits(param), bits(r, g, b of a
+//           solid-colour texture)
 //   xforms  2 x float4 per placement: sin, cos, 0, 0 | offset.xyz, 0
 // A leaf wrapped in Move/RotateY stays in object space; the ray is taken into
 // object space at the leaf exactly as Ray::hit_anything does (src/math/ray.rs:207-247),
@@ -93,17 +96,25 @@ struct DScene {
     const float4* quads;
     const uint4* quad_meta;
     const DMedium* media;
+    const uint4* medium_meta;
     const uint32_t* boundary_refs;
     const float4* xforms;      // 2 x float4 per placement
     const DMaterial* materials;
     const DTexture* textures;
     const DImage* images;
     const DPerlin* perlins;
-    uint32_t root;             // child reference of the whole world (REF_NONE when empty)
+    uint32_t root;             // child reference of the tree (REF_NONE when it is empty)
     uint32_t n_nodes;
     uint32_t n_media;
     uint32_t n_materials;
+    uint32_t n_global;         // leaves kept out of the tree: tested first for every ray
+    uint32_t global_refs[7];
 };
+
+// Shading classes: rays of one class run the same code, so the shade kernel groups the rays of
+// a tile by class before it processes them.
+static constexpr uint32_t CLS_MISS = 0, CLS_LIGHT = 1, CLS_LAMBERTIAN = 2, CLS_METAL = 3, CLS_DIELECTRIC = 4, CLS_ISOTROPIC = 5,
+                          CLS_TEXTURED = 6, N_SHADE_CLASSES = 7;
 
 struct DCamera {
     float3 centre, pixel00, du, dv, ddu, ddv, background;

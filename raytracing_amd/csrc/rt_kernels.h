@@ -22,9 +22,12 @@ void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam
                          unsigned long long n, rt_ray* out);
 void launch_extend(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
                    uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits, DCounters* counters);
+// counts[bounce] in, counts[bounce + 1] out; tex_count / tex_list: this bounce's list of hits on
+// textured materials (filled by the first kernel, consumed by the second).
 void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const DCamera& cam, const BatchInfo& b,
-                  uint64_t seed, uint32_t bounce, uint32_t* counts, const float4* ray_o, const float4* ray_d, const float4* thr,
-                  const uint2* hits, float4* out_o, float4* out_d, float4* out_thr, float4* radiance);
+                  uint64_t seed, uint32_t bounce, uint32_t* counts, uint32_t* tex_count, uint32_t* tex_list, const float4* ray_o,
+                  const float4* ray_d, const float4* thr, const uint2* hits, float4* out_o, float4* out_d, float4* out_thr, float4* radiance,
+                  bool scene_has_textures);
 void launch_accumulate(hipStream_t st, uint32_t max_blocks, const BatchInfo& b, const float4* radiance, float4* acc);
 void launch_finalize(hipStream_t st, uint32_t max_blocks, const float4* acc, unsigned long long n_pixels, float inv_samples, int mode,
                      float exposure, void* out);

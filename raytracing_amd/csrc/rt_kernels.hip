@@ -17,6 +17,8 @@
 // access is a contiguous 1 KiB (float4) or 512 B (uint2) segment.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "rt_device.h"
 #include "rt_kernels.h"
 
@@ -100,7 +102,7 @@ RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float ti
         if (COUNT) pr.spheres++;
         float4 s = sc.spheres[idx];
         if (ref_placed(ref)) {
-            ray_to_object(sc, sc.sphere_meta[idx].z, o, d);
+            ray_to_object(sc, sc.sphere_meta[2 * (size_t)idx].z, o, d);
             a = dot3(d, d);
         }
         return sphere_root(f3(s), s.w, o, d, a, tmin, tmax, t);
@@ -108,7 +110,7 @@ RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float ti
         if (COUNT) pr.spheres++;
         float4 s0 = sc.moving[2 * (size_t)idx], s1 = sc.moving[2 * (size_t)idx + 1];
         if (ref_placed(ref)) {
-            ray_to_object(sc, sc.moving_meta[idx].z, o, d);
+            ray_to_object(sc, sc.moving_meta[2 * (size_t)idx].z, o, d);
             a = dot3(d, d);
         }
         float3 c = f3(s0) + time * f3(s1);  // MovingSphere::hit, src/hittable.rs:310
@@ -173,89 +175,173 @@ RT_D bool medium_root(const DScene& sc, uint32_t idx, float3 o, float3 d, float 
 }
 
 // ---------------------------------------------------------------------------
-// Closest hit over the flattened BVH.  Returns the leaf reference (REF_NONE on
-// a miss) and its t.  Near child first; the far child's entry distance is kept
-// on the stack so that it can be dropped once a closer hit is known.
+// Traversal state and stacks.  A stack entry is (child reference, entry
+// distance of its box); entries that start beyond the closest hit found so far
+// are dropped when popped.
+// ---------------------------------------------------------------------------
+static constexpr uint32_t REF_DONE = 0xFFFFFFFEu;  // traversal finished (never a valid reference)
+
+struct PrivateStack {  // per-lane array (scratch memory): used by the record-based entry points
+    uint32_t ref[STACK_SIZE];
+    float t[STACK_SIZE];
+    int sp = 0;
+    RT_D void push(uint32_t r, float tt) { ref[sp] = r; t[sp] = tt; ++sp; }
+    RT_D bool pop(uint32_t& r, float& tt) {
+        if (sp == 0) return false;
+        --sp;
+        r = ref[sp];
+        tt = t[sp];
+        return true;
+    }
+};
+
+// The first LDS_STACK levels live in LDS, laid out [level][lane] so that the 64 lanes of a
+// wave always hit 64 different banks whatever their stack depths; deeper levels (10 M-leaf
+// trees) spill to a per-lane array.
+static constexpr int LDS_STACK = 16;
+struct LdsStack {
+    uint32_t* lref;  // this lane's column: level k at lref[64 * k]
+    float* lt;
+    uint32_t oref[STACK_SIZE - LDS_STACK];
+    float ot[STACK_SIZE - LDS_STACK];
+    int sp = 0;
+    RT_D void push(uint32_t r, float tt) {
+        if (sp < LDS_STACK) { lref[64 * sp] = r; lt[64 * sp] = tt; }
+        else { oref[sp - LDS_STACK] = r; ot[sp - LDS_STACK] = tt; }
+        ++sp;
+    }
+    RT_D bool pop(uint32_t& r, float& tt) {
+        if (sp == 0) return false;
+        --sp;
+        if (sp < LDS_STACK) { r = lref[64 * sp]; tt = lt[64 * sp]; }
+        else { r = oref[sp - LDS_STACK]; tt = ot[sp - LDS_STACK]; }
+        return true;
+    }
+};
+
+struct TravRay {
+    float3 o, d, inv;
+    float time, a, tmin;
+};
+
+RT_D TravRay make_trav_ray(float3 o, float3 d, float time, float tmin) {
+    TravRay r;
+    r.o = o; r.d = d; r.time = time; r.tmin = tmin;
+    r.a = dot3(d, d);
+    r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    return r;
+}
+
+// Next reference to process after the current one is finished: pops until an entry that can
+// still hold a closer hit, REF_DONE when the stack runs out.
+template <class Stack>
+RT_D uint32_t pop_next(Stack& st, float tmax) {
+    uint32_t r;
+    float tt;
+    while (st.pop(r, tt))
+        if (tt <= tmax) return r;
+    return REF_DONE;
+}
+
+// One inner node: slab-tests both children, continues with the nearer one and stacks the
+// other.  Returns the next reference (inner node, leaf, or REF_DONE).
+template <bool COUNT, class Stack>
+RT_D uint32_t node_step(const DScene& sc, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr) {
+    if (COUNT) pr.nodes++;
+    const float4* n = sc.nodes + 4 * (size_t)cur;
+    float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+    float l_in, r_in, l_out, r_out;
+    {
+#pragma clang fp contract(fast)
+        // NaNs (0 * inf) drop out of fminf/fmaxf, as they do out of simd_min/simd_max in the reference
+        float lx0 = (n0.x - r.o.x) * r.inv.x, lx1 = (n0.w - r.o.x) * r.inv.x;
+        float ly0 = (n0.y - r.o.y) * r.inv.y, ly1 = (n1.x - r.o.y) * r.inv.y;
+        float lz0 = (n0.z - r.o.z) * r.inv.z, lz1 = (n1.y - r.o.z) * r.inv.z;
+        float rx0 = (n1.z - r.o.x) * r.inv.x, rx1 = (n2.y - r.o.x) * r.inv.x;
+        float ry0 = (n1.w - r.o.y) * r.inv.y, ry1 = (n2.z - r.o.y) * r.inv.y;
+        float rz0 = (n2.x - r.o.z) * r.inv.z, rz1 = (n2.w - r.o.z) * r.inv.z;
+        l_in = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), r.tmin));
+        l_out = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), tmax));
+        r_in = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), r.tmin));
+        r_out = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), tmax));
+    }
+    uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+    // Inner boxes (and the world-space bounds of placed leaves and media) are conservative:
+    // their exit distance is widened by 2 ulp.  The box of a leaf that sits in world space
+    // is the reference's own AABB and is tested exactly as AABBx2::hit does
+    // (src/math/aabb.rs:127-167), so the same leaves get tested as in the reference.
+    bool hl = l_in <= l_out * (exact_leaf_box(left) ? 1.0f : 1.0000002f);
+    bool hr = r_in <= r_out * (exact_leaf_box(right) ? 1.0f : 1.0000002f);
+    if (hl && hr) {
+        bool left_first = l_in <= r_in;
+        st.push(left_first ? right : left, left_first ? r_in : l_in);
+        return left_first ? left : right;
+    }
+    if (hl) return left;
+    if (hr) return right;
+    return pop_next(st, tmax);
+}
+
+// One leaf: primitive or medium test; a hit shrinks tmax.  Returns the next reference.
+template <bool COUNT, class Stack>
+RT_D uint32_t leaf_step(const DScene& sc, const TravRay& r, uint32_t cur, float& tmax, uint32_t& best, const MediumKey& key, Stack& st,
+                        Probe& pr) {
+    float t;
+    bool hit;
+    if (ref_kind(cur) == KIND_MEDIUM) hit = medium_root<COUNT>(sc, ref_index(cur), r.o, r.d, r.time, r.a, r.tmin, tmax, key, t, pr);
+    else hit = leaf_root<COUNT>(sc, cur, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr);
+    if (hit) {
+        tmax = t;
+        best = cur;
+    }
+    return pop_next(st, tmax);
+}
+
+// Leaves whose boxes span (almost) the whole scene are kept out of the tree and tested first,
+// by every lane at once.  A sphere still passes through the reference's box test of that leaf
+// (AABB::from_points(c - r, c + r), src/hittable.rs:160-163) before Sphere::hit is evaluated.
+template <bool COUNT>
+RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_t& best, const MediumKey& key, Probe& pr) {
+    for (uint32_t g = 0; g < sc.n_global; ++g) {
+        uint32_t ref = sc.global_refs[g];
+        float t;
+        bool hit;
+        if (ref_kind(ref) == KIND_MEDIUM) {
+            hit = medium_root<COUNT>(sc, ref_index(ref), r.o, r.d, r.time, r.a, r.tmin, tmax, key, t, pr);
+        } else {
+            float4 s = sc.spheres[ref_index(ref)];
+            float x0 = ((s.x - s.w) - r.o.x) * r.inv.x, x1 = ((s.x + s.w) - r.o.x) * r.inv.x;
+            float y0 = ((s.y - s.w) - r.o.y) * r.inv.y, y1 = ((s.y + s.w) - r.o.y) * r.inv.y;
+            float z0 = ((s.z - s.w) - r.o.z) * r.inv.z, z1 = ((s.z + s.w) - r.o.z) * r.inv.z;
+            float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), r.tmin));
+            float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+            hit = t_in <= t_out && leaf_root<COUNT>(sc, ref, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr);
+        }
+        if (hit) {
+            tmax = t;
+            best = ref;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Closest hit over the flattened BVH (one ray per call): returns the leaf
+// reference (REF_NONE on a miss) and its t.
 // ---------------------------------------------------------------------------
 template <bool COUNT>
 RT_D uint32_t closest_hit(const DScene& sc, float3 o, float3 d, float time, float tmin, float tmax, const MediumKey& key, float& t_hit,
                           Probe& pr) {
     uint32_t best = REF_NONE;
-    uint32_t cur = sc.root;
-    if (cur == REF_NONE) return best;
-    const float a = dot3(d, d);
-    const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    uint32_t stack_ref[STACK_SIZE];
-    float stack_t[STACK_SIZE];
-    int sp = 0;
-
-    for (;;) {
-        while (!ref_is_leaf(cur)) {
-            if (COUNT) pr.nodes++;
-            const float4* n = sc.nodes + 4 * (size_t)cur;
-            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-            bool hl, hr;
-            float l_in, r_in, l_out, r_out;
-            {
-#pragma clang fp contract(fast)
-            // slab test of both children; NaNs (0 * inf) drop out of fminf/fmaxf
-            float lx0 = (n0.x - o.x) * inv.x, lx1 = (n0.w - o.x) * inv.x;
-            float ly0 = (n0.y - o.y) * inv.y, ly1 = (n1.x - o.y) * inv.y;
-            float lz0 = (n0.z - o.z) * inv.z, lz1 = (n1.y - o.z) * inv.z;
-            float rx0 = (n1.z - o.x) * inv.x, rx1 = (n2.y - o.x) * inv.x;
-            float ry0 = (n1.w - o.y) * inv.y, ry1 = (n2.z - o.y) * inv.y;
-            float rz0 = (n2.x - o.z) * inv.z, rz1 = (n2.w - o.z) * inv.z;
-            l_in = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), tmin));
-            l_out = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), tmax));
-            r_in = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), tmin));
-            r_out = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), tmax));
-            }
-            uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
-            // Inner boxes (and the world-space bounds of placed leaves and media) are conservative:
-            // their exit distance is widened by 2 ulp.  The box of a leaf that sits in world space
-            // is the reference's own AABB and is tested exactly as AABBx2::hit does
-            // (src/math/aabb.rs:127-167), so the same leaves get tested as in the reference.
-            hl = l_in <= l_out * (exact_leaf_box(left) ? 1.0f : 1.0000002f);
-            hr = r_in <= r_out * (exact_leaf_box(right) ? 1.0f : 1.0000002f);
-            if (hl && hr) {
-                bool left_first = l_in <= r_in;
-                uint32_t far = left_first ? right : left;
-                float far_t = left_first ? r_in : l_in;
-                cur = left_first ? left : right;
-                stack_ref[sp] = far;
-                stack_t[sp] = far_t;
-                ++sp;
-            } else if (hl) {
-                cur = left;
-            } else if (hr) {
-                cur = right;
-            } else {
-                cur = REF_NONE;
-                break;
-            }
-        }
-        if (cur != REF_NONE) {
-            uint32_t kind = ref_kind(cur), idx = ref_index(cur);
-            float t;
-            bool hit;
-            if (kind == KIND_MEDIUM) hit = medium_root<COUNT>(sc, idx, o, d, time, a, tmin, tmax, key, t, pr);
-            else hit = leaf_root<COUNT>(sc, cur, o, d, time, a, tmin, tmax, t, pr);
-            if (hit) {
-                tmax = t;
-                best = cur;
-            }
-        }
-        // pop, skipping subtrees that start beyond the closest hit so far
-        for (;;) {
-            if (sp == 0) {
-                t_hit = tmax;
-                return best;
-            }
-            --sp;
-            cur = stack_ref[sp];
-            if (stack_t[sp] <= tmax) break;
-        }
+    TravRay r = make_trav_ray(o, d, time, tmin);
+    global_leaves<COUNT>(sc, r, tmax, best, key, pr);
+    PrivateStack st;
+    uint32_t cur = sc.root == REF_NONE ? REF_DONE : sc.root;
+    while (cur != REF_DONE) {
+        if (!ref_is_leaf(cur)) cur = node_step<COUNT>(sc, r, cur, tmax, st, pr);
+        else cur = leaf_step<COUNT>(sc, r, cur, tmax, best, key, st, pr);
     }
+    t_hit = tmax;
+    return best;
 }
 
 // ---------------------------------------------------------------------------
@@ -322,11 +408,11 @@ RT_D HitGeom resolve_hit(const DScene& sc, uint32_t ref, float3 o, float3 d, flo
         if (kind == KIND_SPHERE) {
             float4 s = sc.spheres[idx];
             c = f3(s); r = s.w;
-            meta = sc.sphere_meta[idx];
+            meta = sc.sphere_meta[2 * (size_t)idx];
         } else {
             float4 s0 = sc.moving[2 * (size_t)idx], s1 = sc.moving[2 * (size_t)idx + 1];
             c = f3(s0) + time * f3(s1); r = s0.w;
-            meta = sc.moving_meta[idx];
+            meta = sc.moving_meta[2 * (size_t)idx];
         }
         if (ref_placed(ref)) {
             xf = meta.z;
@@ -392,8 +478,46 @@ RT_D float perlin_turbulance(const DPerlin& pn, float3 p, int depth) {
     return fabsf(accum);
 }
 
-// Texture::value (src/texture.rs:40-73)
-RT_D float3 texture_value(const DScene& sc, uint32_t tex_id, HitGeom& g) {
+// What Material::{emitted, scatter} need to know about a hit's material: kind, parameter and
+// its texture (the colour itself when the texture is a solid colour).
+struct ShadeRec {
+    uint32_t kind, tex_kind, tex_id;
+    float param;
+    float3 colour;
+};
+
+// From the material table (two dependent reads): entry points that are handed a MaterialId.
+RT_D ShadeRec shade_rec_of_material(const DScene& sc, uint32_t material) {
+    DMaterial m = sc.materials[material];
+    DTexture t = sc.textures[m.texture];
+    ShadeRec r;
+    r.kind = m.kind; r.param = m.param; r.tex_kind = t.kind; r.tex_id = m.texture; r.colour = f3(t.r, t.g, t.b);
+    return r;
+}
+
+// From the leaf's own 32-byte record (one read): the render path.
+RT_D const uint4* leaf_meta(const DScene& sc, uint32_t ref) {
+    size_t i = 2 * (size_t)ref_index(ref);
+    switch (ref_kind(ref)) {
+        case KIND_SPHERE: return sc.sphere_meta + i;
+        case KIND_MOVING: return sc.moving_meta + i;
+        case KIND_QUAD: return sc.quad_meta + i;
+        default: return sc.medium_meta + i;
+    }
+}
+RT_D ShadeRec shade_rec_of_leaf(const DScene& sc, uint4 m0, uint4 m1) {
+    ShadeRec r;
+    r.kind = (m0.w >> 8) & 0xFFu;
+    r.tex_kind = (m0.w >> 16) & 0xFFu;
+    r.param = __uint_as_float(m1.x);
+    r.colour = f3(__uint_as_float(m1.y), __uint_as_float(m1.z), __uint_as_float(m1.w));
+    r.tex_id = 0;
+    if (r.tex_kind != RT_TEX_SOLID) r.tex_id = sc.materials[m0.x].texture;
+    return r;
+}
+
+// Texture::value (src/texture.rs:40-73) for textures that are not a plain colour
+RT_D float3 texture_value_slow(const DScene& sc, uint32_t tex_id, HitGeom& g) {
     DTexture t = sc.textures[tex_id];
     for (int guard = 0; guard < 16 && t.kind == RT_TEX_CHECKER; ++guard) {
         float sum = floorf(t.scale * g.p.x) + floorf(t.scale * g.p.y) + floorf(t.scale * g.p.z);
@@ -425,6 +549,12 @@ RT_D float3 texture_value(const DScene& sc, uint32_t tex_id, HitGeom& g) {
     return f3(0, 0, 0);
 }
 
+template <bool TEXTURES>
+RT_D float3 texture_value(const DScene& sc, const ShadeRec& rec, HitGeom& g) {
+    if (!TEXTURES || rec.tex_kind == RT_TEX_SOLID) return rec.colour;
+    return texture_value_slow(sc, rec.tex_id, g);
+}
+
 // Vec3::random_unit (src/math/vec3.rs:57-67)
 RT_D float3 random_unit(Rng& rng) {
     for (;;) {
@@ -450,20 +580,22 @@ struct ScatterResult {
     bool scattered;
 };
 
-// Material::emitted + Material::scatter (src/material.rs:65-122)
-RT_D ScatterResult shade_hit(const DScene& sc, HitGeom& g, float3 d_in, Rng& rng) {
+// Material::emitted + Material::scatter (src/material.rs:65-122).  Every kind evaluates its
+// texture exactly once (attenuation, or the emitted colour of a light), so that is done first.
+template <bool TEXTURES>
+RT_D ScatterResult shade_hit(const DScene& sc, const ShadeRec& m, HitGeom& g, float3 d_in, Rng& rng) {
     ScatterResult r;
     r.emitted = f3(0, 0, 0);
     r.attenuation = f3(0, 0, 0);
     r.dir = f3(0, 0, 0);
     r.scattered = false;
-    DMaterial m = sc.materials[g.material];
+    float3 tex = texture_value<TEXTURES>(sc, m, g);
     switch (m.kind) {
         case RT_MAT_LAMBERTIAN: {
             float3 dir = g.normal + random_unit(rng);
             if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = g.normal;
             r.dir = dir;
-            r.attenuation = texture_value(sc, m.texture, g);
+            r.attenuation = tex;
             r.scattered = true;
             break;
         }
@@ -474,13 +606,13 @@ RT_D ScatterResult shade_hit(const DScene& sc, HitGeom& g, float3 d_in, Rng& rng
             float3 dir = reflected + fuzz * random_unit(rng);
             if (dot3(dir, g.normal) > 0.0f) {
                 r.dir = dir;
-                r.attenuation = texture_value(sc, m.texture, g);
+                r.attenuation = tex;
                 r.scattered = true;
             }
             break;
         }
         case RT_MAT_DIELECTRIC: {
-            r.attenuation = texture_value(sc, m.texture, g);
+            r.attenuation = tex;
             float ratio = g.front_face ? 1.0f / m.param : m.param;
             float3 ud = unit3(d_in);
             float cos_theta = fminf(dot3(-ud, g.normal), 1.0f);
@@ -499,12 +631,12 @@ RT_D ScatterResult shade_hit(const DScene& sc, HitGeom& g, float3 d_in, Rng& rng
         }
         case RT_MAT_ISOTROPIC: {
             r.dir = random_unit(rng);
-            r.attenuation = texture_value(sc, m.texture, g);
+            r.attenuation = tex;
             r.scattered = true;
             break;
         }
         case RT_MAT_DIFFUSE_LIGHT: {
-            r.emitted = texture_value(sc, m.texture, g);
+            r.emitted = tex;
             break;
         }
         default: break;
@@ -597,80 +729,281 @@ __global__ __launch_bounds__(256) void k_primary_rays(DCamera cam, uint64_t seed
     }
 }
 
+// Extend: closest hit for every ray of the current queue.
+//
+// Persistent waves: wave w owns every n_waves-th 64-ray block of the queue and its 64 lanes
+// pull rays from them one by one, so a lane that finishes a short ray starts the next
+// instead of idling until the longest ray of a 64-ray batch is done.  Inside the loop the
+// wave alternates between an inner-node phase (run while at least INNER_MIN lanes are at inner
+// nodes, or nobody waits at a leaf) and a leaf phase, which keeps lanes that do the same kind
+// of work together.
+static constexpr int EXTEND_BLOCK = 256;
+static constexpr int INNER_MIN = 20;
+
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce, const uint32_t* __restrict__ counts,
-                                                const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                uint2* __restrict__ hits, DCounters* counters) {
+__global__ __launch_bounds__(EXTEND_BLOCK) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
+                                                         const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
+                                                         const float4* __restrict__ ray_d, uint2* __restrict__ hits, DCounters* counters) {
+    __shared__ uint32_t s_ref[EXTEND_BLOCK / 64][LDS_STACK][64];
+    __shared__ float s_t[EXTEND_BLOCK / 64][LDS_STACK][64];
     const uint32_t n = counts[bounce];
+    const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * (EXTEND_BLOCK / 64) + wave_in_block, n_waves = gridDim.x * (EXTEND_BLOCK / 64);
+    // Work of this wave: the 64-ray blocks w, w + n_waves, w + 2 n_waves, ... of the queue.  Interleaving
+    // spreads expensive image regions over all waves (a contiguous slice per wave does not: the rows of
+    // an image differ a lot in cost), with no atomics.
+    uint32_t blk = wave;
+    if ((unsigned long long)blk * 64ull >= n) return;
+    uint32_t next = blk * 64u;
+    uint32_t blk_end = min(n, next + 64u);
+
+    LdsStack st;
+    st.lref = &s_ref[wave_in_block][0][lane];
+    st.lt = &s_t[wave_in_block][0][lane];
     Probe pr;
     uint32_t segs = 0, nhit = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float4 ro = ray_o[i], rd = ray_d[i];
-        uint32_t path = __float_as_uint(rd.w);
-        uint32_t s_local = path / b.n_pixels;
-        MediumKey key{seed, b.first_pixel + (path - s_local * b.n_pixels), b.first_sample + s_local, bounce};
-        float t;
-        uint32_t ref = closest_hit<COUNT>(sc, f3(ro), f3(rd), ro.w, 0.001f, RT_INF, key, t, pr);
-        hits[i] = make_uint2(__float_as_uint(t), ref);
-        if (COUNT) { segs++; nhit += (ref != REF_NONE); }
+
+    uint32_t mine = REF_NONE;  // queue slot this lane is working on
+    uint32_t cur = REF_DONE, best = REF_NONE;
+    float tmax = RT_INF;
+    TravRay r;
+    MediumKey key{seed, 0, 0, bounce};
+    const uint32_t root = sc.root == REF_NONE ? REF_DONE : sc.root;
+
+    for (;;) {
+        // retire finished rays, hand out new ones
+        if (mine != REF_NONE && cur == REF_DONE) {
+            hits[mine] = make_uint2(__float_as_uint(tmax), best);
+            if (COUNT) { segs++; nhit += (best != REF_NONE); }
+            mine = REF_NONE;
+        }
+        unsigned long long idle = __ballot(mine == REF_NONE);
+        if (idle) {
+            if (next == blk_end && next < n) {  // block used up: on to this wave's next one
+                unsigned long long nb = ((unsigned long long)blk + n_waves) * 64ull;
+                blk += n_waves;
+                next = (uint32_t)min(nb, (unsigned long long)n);
+                blk_end = (uint32_t)min(nb + 64ull, (unsigned long long)n);
+            }
+            uint32_t avail = blk_end - next;
+            if (avail) {
+                uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (mine == REF_NONE && rank < avail) {
+                    mine = next + rank;
+                    float4 ro = ray_o[mine], rd = ray_d[mine];
+                    uint32_t path = __float_as_uint(rd.w);
+                    uint32_t s_local = path / b.n_pixels;
+                    key.pixel = b.first_pixel + (path - s_local * b.n_pixels);
+                    key.sample = b.first_sample + s_local;
+                    r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
+                    tmax = RT_INF;
+                    best = REF_NONE;
+                    st.sp = 0;
+                    global_leaves<COUNT>(sc, r, tmax, best, key, pr);
+                    cur = root;
+                }
+                next += min((uint32_t)__popcll(idle), avail);
+            } else if (idle == ~0ull) {
+                break;
+            }
+        }
+        // inner-node phase
+        for (;;) {
+            bool at_inner = mine != REF_NONE && cur != REF_DONE && !ref_is_leaf(cur);
+            unsigned long long m = __ballot(at_inner);
+            if (m == 0) break;
+            if (__popcll(m) < INNER_MIN && __ballot(mine != REF_NONE && cur != REF_DONE && ref_is_leaf(cur)) != 0) break;
+            if (at_inner) cur = node_step<COUNT>(sc, r, cur, tmax, st, pr);
+        }
+        // leaf phase
+        if (mine != REF_NONE && cur != REF_DONE && ref_is_leaf(cur)) cur = leaf_step<COUNT>(sc, r, cur, tmax, best, key, st, pr);
     }
     if (COUNT) flush_probe(counters, pr, segs, nhit);
 }
 
-__global__ __launch_bounds__(256) void k_shade(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce, uint32_t* __restrict__ counts,
-                                               const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                               const float4* __restrict__ thr, const uint2* __restrict__ hits,
-                                               float4* __restrict__ out_o, float4* __restrict__ out_d, float4* __restrict__ out_thr,
-                                               float4* __restrict__ radiance) {
+// One (ray, hit) pair through ray_colour's loop body (src/camera.rs:344-361): writes the path's
+// radiance when the path ends here, otherwise returns the next ray.
+template <bool TEXTURES>
+RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, uint64_t seed, uint32_t bounce, float4 ro, float4 rd, float4 th,
+                    uint2 h, float4* __restrict__ radiance, float4& no, float4& nd, float4& nt) {
+    uint32_t path = __float_as_uint(rd.w);
+    float3 T = f3(th);
+    if (h.y == REF_NONE) {  // src/camera.rs:347-349
+        float3 c = T * cam.background;
+        radiance[path] = make_float4(c.x, c.y, c.z, 0.0f);
+        return false;
+    }
+    const uint4* meta = leaf_meta(sc, h.y);
+    uint4 m0 = meta[0], m1 = meta[1];
+    float3 o = f3(ro), d = f3(rd);
+    HitGeom g = resolve_hit(sc, h.y, o, d, ro.w, __uint_as_float(h.x));
+    ShadeRec rec = shade_rec_of_leaf(sc, m0, m1);
+    uint32_t s_local = path / b.n_pixels;
+    Rng rng;
+    rng.init(path_key(seed, b.first_pixel + (path - s_local * b.n_pixels), b.first_sample + s_local), bounce, STREAM_SCATTER);
+    ScatterResult r = shade_hit<TEXTURES>(sc, rec, g, d, rng);
+    if (!r.scattered) {  // src/camera.rs:354-355
+        float3 c = T * r.emitted;
+        radiance[path] = make_float4(c.x, c.y, c.z, 0.0f);
+        return false;
+    }
+    if (bounce + 1 >= cam.max_depth) {  // depth exhausted, src/camera.rs:342
+        radiance[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return false;
+    }
+    float3 nT = T * r.attenuation + r.emitted;  // src/camera.rs:360
+    no = make_float4(g.p.x, g.p.y, g.p.z, ro.w);
+    nd = make_float4(r.dir.x, r.dir.y, r.dir.z, rd.w);
+    nt = make_float4(nT.x, nT.y, nT.z, 0.0f);
+    return true;
+}
+
+// Shade: Material::emitted / scatter for every (ray, hit) of the current queue.
+//
+// A block takes a tile of SHADE_TILE consecutive queue slots, reads their hit records, looks up
+// each leaf's shading class (one cached 16-byte read) and counting-sorts the tile by class in
+// LDS.  The threads then walk the tile in sorted order, so that the 64 lanes of a wave run the
+// same material code on (almost always) the same class; the ray records they read all lie inside
+// the tile, i.e. in cache lines the block consumes completely.  Hits on materials whose texture
+// is not a plain colour (checker, image, perlin noise) are only listed here; k_shade_textured
+// handles them, which keeps the register footprint of this kernel small.
+static constexpr int SHADE_BLOCK = 256;
+static constexpr int SHADE_PER_THREAD = 2;
+static constexpr int SHADE_TILE = SHADE_BLOCK * SHADE_PER_THREAD;
+
+// Survivors of a tile are staged in LDS and appended to the next queue with ONE global atomic per
+// tile (a per-wave atomic on the single queue counter serialises the whole chip: 2.5 M atomics
+// per 4-spp pass of the 4K image cost more than all the shading), then copied out with
+// consecutive lanes writing consecutive slots.
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce,
+                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ tex_count,
+                                                       uint32_t* __restrict__ tex_list, const float4* __restrict__ ray_o,
+                                                       const float4* __restrict__ ray_d, const float4* __restrict__ thr,
+                                                       const uint2* __restrict__ hits, float4* __restrict__ out_o,
+                                                       float4* __restrict__ out_d, float4* __restrict__ out_thr,
+                                                       float4* __restrict__ radiance) {
+    __shared__ float4 s_out[3][SHADE_TILE];
+    __shared__ uint16_t s_order[SHADE_TILE];
+    __shared__ uint32_t s_count[N_SHADE_CLASSES];
+    __shared__ uint32_t s_offset[N_SHADE_CLASSES + 1];
+    __shared__ uint32_t s_alive, s_base, s_tex_base;
     const uint32_t n = counts[bounce];
-    const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
-        const uint32_t i = base + threadIdx.x;
-        bool alive = false;
-        float4 no, nd, nt;
-        if (i < n) {
-            float4 ro = ray_o[i], rd = ray_d[i], th = thr[i];
-            uint2 h = hits[i];
-            uint32_t path = __float_as_uint(rd.w);
-            float3 T = f3(th);
-            if (h.y == REF_NONE) {  // src/camera.rs:347-349
-                float3 c = T * cam.background;
-                radiance[path] = make_float4(c.x, c.y, c.z, 0.0f);
-            } else {
-                float3 o = f3(ro), d = f3(rd);
-                HitGeom g = resolve_hit(sc, h.y, o, d, ro.w, __uint_as_float(h.x));
-                uint32_t s_local = path / b.n_pixels;
-                Rng rng;
-                rng.init(path_key(seed, b.first_pixel + (path - s_local * b.n_pixels), b.first_sample + s_local), bounce, STREAM_SCATTER);
-                ScatterResult r = shade_hit(sc, g, d, rng);
-                if (!r.scattered) {  // src/camera.rs:354-355
-                    float3 c = T * r.emitted;
-                    radiance[path] = make_float4(c.x, c.y, c.z, 0.0f);
-                } else if (bounce + 1 >= cam.max_depth) {  // depth exhausted, src/camera.rs:342
-                    radiance[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                } else {
-                    float3 nT = T * r.attenuation + r.emitted;  // src/camera.rs:360
-                    alive = true;
-                    no = make_float4(g.p.x, g.p.y, g.p.z, ro.w);
-                    nd = make_float4(r.dir.x, r.dir.y, r.dir.z, rd.w);
-                    nt = make_float4(nT.x, nT.y, nT.z, 0.0f);
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t tile = blockIdx.x * SHADE_TILE; tile < n; tile += gridDim.x * SHADE_TILE) {
+        const uint32_t tile_n = min((uint32_t)SHADE_TILE, n - tile);
+        if (tid < N_SHADE_CLASSES) s_count[tid] = 0;
+        if (tid == 0) s_alive = 0;
+        __syncthreads();
+        // classify; rank inside (wave, class) by ballot, one LDS atomic per wave and class
+        uint32_t cls[SHADE_PER_THREAD], pos[SHADE_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < SHADE_PER_THREAD; ++k) {
+            uint32_t e = k * SHADE_BLOCK + tid;
+            uint32_t c = N_SHADE_CLASSES;  // no entry
+            if (e < tile_n) {
+                uint32_t ref = hits[tile + e].y;
+                c = ref == REF_NONE ? CLS_MISS : (leaf_meta(sc, ref)->w & 0xFFu);
+            }
+            cls[k] = c;
+            pos[k] = 0;
+            for (uint32_t q = 0; q < N_SHADE_CLASSES; ++q) {
+                unsigned long long m = __ballot(c == q);
+                if (m) {
+                    uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u, base = 0;
+                    if (lane == leader) base = atomicAdd(&s_count[q], (uint32_t)__popcll(m));
+                    base = __shfl(base, (int)leader, 64);
+                    if (c == q) pos[k] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 }
             }
         }
-        // queue compaction: one atomic per wave reserves a contiguous run of slots
-        unsigned long long mask = __ballot(alive);
-        if (mask) {
-            uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-            uint32_t slot0 = 0;
-            if (lane == leader) slot0 = atomicAdd(&counts[bounce + 1], (uint32_t)__popcll(mask));
-            slot0 = __shfl(slot0, (int)leader, 64);
-            if (alive) {
-                uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                out_o[slot] = no;
-                out_d[slot] = nd;
-                out_thr[slot] = nt;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (uint32_t q = 0; q < N_SHADE_CLASSES; ++q) { s_offset[q] = run; run += s_count[q]; }
+            s_offset[N_SHADE_CLASSES] = run;
+            // hits on textured materials (the last class) go to this bounce's list: one atomic per tile
+            uint32_t n_tex = s_count[CLS_TEXTURED];
+            s_tex_base = n_tex ? atomicAdd(tex_count, n_tex) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SHADE_PER_THREAD; ++k)
+            if (cls[k] < N_SHADE_CLASSES) s_order[s_offset[cls[k]] + pos[k]] = (uint16_t)(k * SHADE_BLOCK + tid);
+        __syncthreads();
+        const uint32_t first_textured = s_offset[CLS_TEXTURED];
+
+        for (int k = 0; k < SHADE_PER_THREAD; ++k) {
+            const uint32_t e = k * SHADE_BLOCK + tid;
+            bool alive = false;
+            float4 no, nd, nt;
+            if (e < tile_n) {
+                const uint32_t i = tile + s_order[e];
+                if (e >= first_textured) tex_list[s_tex_base + (e - first_textured)] = i;
+                else alive = shade_one<false>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], thr[i], hits[i], radiance, no, nd, nt);
+            }
+            unsigned long long mask = __ballot(alive);
+            if (mask) {
+                uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u, slot0 = 0;
+                if (lane == leader) slot0 = atomicAdd(&s_alive, (uint32_t)__popcll(mask));
+                slot0 = __shfl(slot0, (int)leader, 64);
+                if (alive) {
+                    uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                    s_out[0][slot] = no;
+                    s_out[1][slot] = nd;
+                    s_out[2][slot] = nt;
+                }
             }
         }
+        __syncthreads();
+        const uint32_t n_alive = s_alive;
+        if (tid == 0 && n_alive) s_base = atomicAdd(&counts[bounce + 1], n_alive);
+        __syncthreads();
+        const uint32_t base = s_base;
+        for (uint32_t j = tid; j < n_alive; j += SHADE_BLOCK) {
+            out_o[base + j] = s_out[0][j];
+            out_d[base + j] = s_out[1][j];
+            out_thr[base + j] = s_out[2][j];
+        }
+        __syncthreads();
+    }
+}
+
+// The hits k_shade set aside: materials with checker, image or perlin-noise textures.  One global
+// atomic per block appends the block's survivors.
+__global__ __launch_bounds__(256) void k_shade_textured(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce,
+                                                        uint32_t* __restrict__ counts, const uint32_t* __restrict__ tex_count,
+                                                        const uint32_t* __restrict__ tex_list, const float4* __restrict__ ray_o,
+                                                        const float4* __restrict__ ray_d, const float4* __restrict__ thr,
+                                                        const uint2* __restrict__ hits, float4* __restrict__ out_o,
+                                                        float4* __restrict__ out_d, float4* __restrict__ out_thr,
+                                                        float4* __restrict__ radiance) {
+    __shared__ uint32_t s_wave_count[4], s_base;
+    const uint32_t n = *tex_count;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t first = blockIdx.x * blockDim.x; first < n; first += gridDim.x * blockDim.x) {
+        const uint32_t j = first + threadIdx.x;
+        bool alive = false;
+        float4 no, nd, nt;
+        if (j < n) {
+            const uint32_t i = tex_list[j];
+            alive = shade_one<true>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], thr[i], hits[i], radiance, no, nd, nt);
+        }
+        unsigned long long mask = __ballot(alive);
+        if (lane == 0) s_wave_count[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
+            s_base = total ? atomicAdd(&counts[bounce + 1], total) : 0u;
+        }
+        __syncthreads();
+        if (alive) {
+            uint32_t slot = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            for (uint32_t w2 = 0; w2 < wave; ++w2) slot += s_wave_count[w2];
+            out_o[slot] = no;
+            out_d[slot] = nd;
+            out_thr[slot] = nt;
+        }
+        __syncthreads();
     }
 }
 
@@ -762,7 +1095,8 @@ __global__ __launch_bounds__(256) void k_shade_records(DScene sc, uint64_t seed,
         g.front_face = h.front_face != 0u;
         Rng rng;
         rng.init(path_key(seed, r.rng_pixel, r.rng_sample), r.rng_bounce, STREAM_SCATTER);
-        ScatterResult s = shade_hit(sc, g, f3(r.direction[0], r.direction[1], r.direction[2]), rng);
+        ShadeRec rec = shade_rec_of_material(sc, h.material);
+        ScatterResult s = shade_hit<true>(sc, rec, g, f3(r.direction[0], r.direction[1], r.direction[2]), rng);
         rt_ray o = rt_ray{};
         if (s.scattered) {
             o.origin[0] = g.p.x; o.origin[1] = g.p.y; o.origin[2] = g.p.z; o.time = r.time;
@@ -799,16 +1133,23 @@ void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam
 
 void launch_extend(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
                    uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits, DCounters* counters) {
-    dim3 grid(grid_for(upper_bound, max_blocks));
-    if (counters) hipLaunchKernelGGL(k_extend<true>, grid, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
-    else hipLaunchKernelGGL(k_extend<false>, grid, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
+    // persistent waves: no more blocks than fit the chip at once (LDS: 32 KiB per block -> 5 per CU)
+    dim3 grid(grid_for(upper_bound, (max_blocks / 8u) * 5u));
+    if (counters) hipLaunchKernelGGL(k_extend<true>, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
+    else hipLaunchKernelGGL(k_extend<false>, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
 }
 
 void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const DCamera& cam, const BatchInfo& b,
-                  uint64_t seed, uint32_t bounce, uint32_t* counts, const float4* ray_o, const float4* ray_d, const float4* thr,
-                  const uint2* hits, float4* out_o, float4* out_d, float4* out_thr, float4* radiance) {
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(upper_bound, max_blocks)), dim3(256), 0, st, sc, cam, b, seed, bounce, counts, ray_o, ray_d, thr,
+                  uint64_t seed, uint32_t bounce, uint32_t* counts, uint32_t* tex_count, uint32_t* tex_list, const float4* ray_o,
+                  const float4* ray_d, const float4* thr, const uint2* hits, float4* out_o, float4* out_d, float4* out_thr, float4* radiance,
+                  bool scene_has_textures) {
+    unsigned long long tiles = ((unsigned long long)upper_bound + SHADE_TILE - 1) / SHADE_TILE;
+    uint32_t grid = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(tiles, 1), max_blocks);
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, st, sc, cam, b, seed, bounce, counts, tex_count, tex_list, ray_o, ray_d, thr,
                        hits, out_o, out_d, out_thr, radiance);
+    if (scene_has_textures)
+        hipLaunchKernelGGL(k_shade_textured, dim3(grid_for(upper_bound, max_blocks)), dim3(256), 0, st, sc, cam, b, seed, bounce, counts,
+                           tex_count, tex_list, ray_o, ray_d, thr, hits, out_o, out_d, out_thr, radiance);
 }
 
 void launch_accumulate(hipStream_t st, uint32_t max_blocks, const BatchInfo& b, const float4* radiance, float4* acc) {
