@@ -144,6 +144,7 @@ def main():
         cnt = scene.counters(reset=True)
         scene.set_counters(False)
         del scratch
+        per_segment = {k: round(cnt[k] / max(1, cnt["segments"]), 3) for k in ("node_visits", "sphere_tests", "quad_tests", "medium_tests", "hits")}
         ext_ms, ext_launches = phases["extend"]
         # segments of the whole timed region: the counted step times the number of steps (steps differ
         # only in their sample numbers; their segment counts agree to ~0.1 %)
@@ -168,7 +169,7 @@ def main():
                     "avg_launch_ms": round(ext_ms / max(1, ext_launches), 5), "segments_per_sample": round(segments / cnt["samples"], 4),
                     "valu": {"achieved": round(achieved_tf, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved_tf / FP32_VECTOR_PEAK_TFLOPS, 5)},
-                    "phase_ms": {k: round(v[0], 3) for k, v in phases.items()}}
+                    "work_per_segment": per_segment, "phase_ms": {k: round(v[0], 3) for k, v in phases.items()}}
         result = {
             "metric": "Msamples/sec (whole node) on Book-2 final scene", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -178,6 +179,7 @@ def main():
                                    "one all-reduce of the accumulation buffer",
                        "width": w, "height": h, "spp_per_step": spp, "max_depth": MAX_DEPTH, "parallelism": f"sample-slice x{world}"},
             "roofline": roofline,
+            "scene": scene.info(),
         }
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_spp)

@@ -302,6 +302,18 @@ int rt_buffer_download(rt_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out);
 int rt_scene_destroy(rt_scene* scene);
 
+/* What rt_scene_create built: size of the flattened BVH, how many leaves are
+ * tested ahead of it, bytes resident on the GPU, host seconds spent building. */
+typedef struct rt_scene_info {
+    uint32_t bvh_nodes;
+    uint32_t bvh_depth;
+    uint32_t leaves_in_tree;
+    uint32_t leaves_tested_first;
+    uint64_t device_bytes;
+    double build_seconds;
+} rt_scene_info;
+int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
+
 /* Replaces `n_samples` consecutive calls of RaytracingCamera::render
  * (src/camera.rs:269-306) with sample numbers first_sample,
  * first_sample+1, ... (the reference counts from 1, src/camera.rs:82-83):

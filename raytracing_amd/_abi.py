@@ -12,7 +12,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
-LIB_AMD_PATH = os.path.join(_HERE, "csrc", "librt_amd.so")
+# RT_AMD_LIBRARY: another build of the same ABI (kernel tuning experiments)
+LIB_AMD_PATH = os.environ.get("RT_AMD_LIBRARY") or os.path.join(_HERE, "csrc", "librt_amd.so")
 LIB_HOST_PATH = os.path.join(_HERE, "host", "librt_host.so")
 EARTH_ASSET = os.path.join(_HERE, "assets", "earthmap_1024x512.rgb8")
 EARTH_SIZE = (1024, 512)
@@ -47,6 +48,11 @@ class RtCounters(C.Structure):
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if not k.startswith("_")}
+
+
+class RtSceneInfo(C.Structure):
+    _fields_ = [("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("leaves_in_tree", C.c_uint32),
+                ("leaves_tested_first", C.c_uint32), ("device_bytes", C.c_uint64), ("build_seconds", C.c_double)]
 
 
 class Leaf(C.Structure):
@@ -100,6 +106,7 @@ RT_ABI = {
     "rt_buffer_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "rt_scene_create": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "rt_scene_destroy": (C.c_int, [_P]),
+    "rt_scene_get_info": (C.c_int, [_P, C.POINTER(RtSceneInfo)]),
     "rt_render_accumulate": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_render_accumulate_device": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_finalize_device": (C.c_int, [_P, _P, _U64, _U32, C.c_int, _F, _P]),

@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -55,6 +57,7 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     uint32_t max_blocks = 2048;
+    uint32_t extend_blocks = 1024;  // persistent grid of the extend kernel: what the chip holds at once
     uint64_t batch_paths = DEFAULT_BATCH_PATHS;
     bool counters_on = false;
     bool phase_timing = false;
@@ -70,6 +73,7 @@ struct rt_ctx {
     uint32_t* counts = nullptr;
     uint32_t counts_cap = 0;
     DCounters* d_counters = nullptr;
+    unsigned long long* stack_overflow = nullptr;  // deep stack levels of the extend kernel's resident waves
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool have_render_time = false;
@@ -86,6 +90,7 @@ struct rt_scene {
     DScene d{};
     uint32_t bvh_depth = 0;
     bool has_textures = false;  // some material's texture is not a plain colour
+    rt_scene_info info{};
 };
 
 namespace {
@@ -234,6 +239,7 @@ template <class T>
 int upload(rt_scene* sc, const std::vector<T>& host, const T** out) {
     *out = nullptr;
     size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
+    sc->info.device_bytes += bytes;
     void* d = nullptr;
     HIP_TRY(hipMalloc(&d, bytes));
     sc->allocations.push_back(d);
@@ -367,8 +373,16 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     rt_ctx* c = new rt_ctx();
     c->device = device_id;
     c->max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
+    {
+        int per_cu = rt::extend_blocks_per_cu();
+        if (const char* e = getenv("RT_AMD_EXTEND_BLOCKS_PER_CU")) per_cu = atoi(e);  // tuning experiments only
+        if (per_cu < 1) per_cu = 4;
+        c->extend_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)per_cu;
+        if (getenv("RT_AMD_VERBOSE")) fprintf(stderr, "[rt_amd] extend kernel: %d blocks per CU, grid %u\n", per_cu, c->extend_blocks);
+    }
     hipError_t e = hipMalloc((void**)&c->d_counters, sizeof(DCounters));
     if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(DCounters));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->stack_overflow, rt::extend_overflow_bytes(c->extend_blocks));
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
     if (e != hipSuccess) {
@@ -386,6 +400,7 @@ int rt_ctx_destroy(rt_ctx* c) {
     free_queues(c);
     if (c->counts) (void)hipFree(c->counts);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->stack_overflow) (void)hipFree(c->stack_overflow);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -505,6 +520,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     int e = validate(desc);
     if (e) return e;
     if ((e = set_device(ctx))) return e;
+    const auto t_begin = std::chrono::steady_clock::now();
 
     std::vector<Xf> xfs(desc->n_transforms);
     std::vector<float4> xforms(2 * (size_t)desc->n_transforms);
@@ -774,9 +790,20 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     sc->d.n_materials = desc->n_materials;
     for (uint32_t i = 0; i < desc->n_materials; ++i)
         if (desc->textures[desc->materials[i].texture].kind != RT_TEX_SOLID) sc->has_textures = true;
+    sc->info.bvh_nodes = bvh.n_nodes;
+    sc->info.bvh_depth = bvh.max_depth;
+    sc->info.leaves_in_tree = (uint32_t)prims.size();
+    sc->info.leaves_tested_first = n_global;
+    sc->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     sc->d.n_global = n_global;
     for (int i = 0; i < 7; ++i) sc->d.global_refs[i] = global_refs[i];
     *out = sc;
+    return RT_OK;
+}
+
+int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
+    if (!sc || !out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = sc->info;
     return RT_OK;
 }
 
@@ -822,7 +849,7 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
             int cur = 0;
             for (uint32_t bounce = 0; bounce < cam->max_depth; ++bounce) {
                 if ((e = phase_begin(c, 1, &ep))) return e;
-                launch_extend(c->stream, c->max_blocks, total, sc->d, b, seed, bounce, c->counts, c->ray_o[cur], c->ray_d[cur], c->hits, counters);
+                launch_extend(c->stream, c->extend_blocks, total, sc->d, b, seed, bounce, c->counts, c->ray_o[cur], c->ray_d[cur], c->hits, c->stack_overflow, counters);
                 if ((e = phase_end(c, ep))) return e;
                 if ((e = phase_begin(c, 2, &ep))) return e;
                 launch_shade(c->stream, c->max_blocks, total, sc->d, dcam, b, seed, bounce, c->counts, c->counts + n_queue_counts + bounce,

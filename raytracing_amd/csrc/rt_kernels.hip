@@ -144,21 +144,61 @@ RT_D bool boundary_root(const DScene& sc, const DMedium& m, float3 o, float3 d, 
 // leaf in world space that is not a medium: top four bits 1kk0 with kk != 11
 RT_D bool exact_leaf_box(uint32_t ref) { return ((ref >> 28) & 9u) == 8u && (ref >> 29) != 7u; }
 
+// What a medium needs to start its random stream: (seed, pixel, sample) of the path and the
+// bounce.  The render path only carries the path's index in the batch and derives the rest
+// when a medium is actually entered.
 struct MediumKey {
     uint64_t seed;
     uint32_t pixel, sample, bounce;
+    RT_D uint64_t path_key_of() const { return path_key(seed, pixel, sample); }
+};
+struct BatchMediumKey {
+    uint64_t seed;
+    uint32_t path, bounce;
+    BatchInfo b;
+    RT_D uint64_t path_key_of() const {
+        uint32_t s_local = path / b.n_pixels;
+        return path_key(seed, b.first_pixel + (path - s_local * b.n_pixels), b.first_sample + s_local);
+    }
 };
 
 // ConstantMediumPhase2 (src/math/ray.rs:131-163): free-path sampling inside
 // [t1, t2] clamped to the current interval.
-template <bool COUNT>
+template <bool COUNT, class Key>
 RT_D bool medium_root(const DScene& sc, uint32_t idx, float3 o, float3 d, float time, float a, float tmin, float tmax,
-                      const MediumKey& key, float& t, Probe& pr) {
+                      const Key& key, float& t, Probe& pr) {
     if (COUNT) pr.media++;
     DMedium m = sc.media[idx];
     float t1, t2;
-    if (!boundary_root<COUNT>(sc, m, o, d, time, a, -RT_INF, RT_INF, t1, pr)) return false;
-    if (!boundary_root<COUNT>(sc, m, o, d, time, a, 0.0001f + t1, RT_INF, t2, pr)) return false;
+    const uint32_t ref0 = sc.boundary_refs[m.first_boundary];
+    if (m.n_boundary == 1 && (ref0 >> 28) == (8u | (KIND_SPHERE << 1))) {
+        // Boundary = one sphere in world space: the two queries share oc, half_b, c and the
+        // square root; each root is then chosen exactly as Sphere::hit chooses it for the
+        // intervals (-inf, inf) and (0.0001 + t1, inf).
+        if (COUNT) pr.spheres += 2;
+        float4 sp = sc.spheres[ref_index(ref0)];
+        float3 oc = o - f3(sp);
+        float half_b = dot3(oc, d);
+        float c = dot3(oc, oc) - sp.w * sp.w;
+        float disc = half_b * half_b - a * c;
+        if (disc < 0.0f) return false;
+        float sq = sqrtf(disc);
+        float near_root = (-half_b - sq) / a, far_root = (-half_b + sq) / a;
+        t1 = near_root;
+        if (!(-RT_INF < t1 && t1 < RT_INF)) {
+            t1 = far_root;
+            if (!(-RT_INF < t1 && t1 < RT_INF)) return false;
+        }
+        float lo = 0.0001f + t1;
+        t2 = near_root;
+        if (!(lo < t2 && t2 < RT_INF)) {
+            t2 = far_root;
+            if (!(lo < t2 && t2 < RT_INF)) return false;
+        }
+    } else {
+        if (!boundary_root<COUNT>(sc, m, o, d, time, a, -RT_INF, RT_INF, t1, pr)) return false;
+        if (!boundary_root<COUNT>(sc, m, o, d, time, a, 0.0001f + t1, RT_INF, t2, pr)) return false;
+    }
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (t1 >= t2) return false;
@@ -166,7 +206,7 @@ RT_D bool medium_root(const DScene& sc, uint32_t idx, float3 o, float3 d, float 
     float ray_len = sqrtf(a);
     float distance_inside = (t2 - t1) * ray_len;
     Rng rng;
-    rng.init(path_key(key.seed, key.pixel, key.sample), key.bounce, STREAM_MEDIUM0 + idx);
+    rng.init(key.path_key_of(), key.bounce, STREAM_MEDIUM0 + idx);
     // f32::log(x, E as f32) = ln(x) / ln(2.7182817f) = ln(x) / 0.99999994f
     float hit_distance = m.neg_inv_density * (logf(rng.next()) / 0.99999994f);
     if (hit_distance > distance_inside) return false;
@@ -195,26 +235,36 @@ struct PrivateStack {  // per-lane array (scratch memory): used by the record-ba
     }
 };
 
+// Stack of the render path's extend kernel.  An entry is 64 bits: (entry distance << 32) | ref.
 // The first LDS_STACK levels live in LDS, laid out [level][lane] so that the 64 lanes of a
-// wave always hit 64 different banks whatever their stack depths; deeper levels (10 M-leaf
-// trees) spill to a per-lane array.
-static constexpr int LDS_STACK = 16;
-struct LdsStack {
-    uint32_t* lref;  // this lane's column: level k at lref[64 * k]
-    float* lt;
-    uint32_t oref[STACK_SIZE - LDS_STACK];
-    float ot[STACK_SIZE - LDS_STACK];
+// wave always hit different banks whatever their stack depths; deeper levels (10 M-leaf trees)
+// go to a per-wave area in global memory with the same layout.  The two address spaces are
+// spelled out so that every access compiles to a plain ds_ or global_ instruction.
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 12
+#endif
+static constexpr int LDS_STACK = RT_LDS_STACK;
+static constexpr int OVERFLOW_STACK = STACK_SIZE - LDS_STACK;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(1))) unsigned long long global_u64;
+struct WaveStack {
+    lds_u64* lds;     // this lane's column: level k at lds[64 * k]
+    global_u64* ovf;  // level LDS_STACK + k at ovf[64 * k]
     int sp = 0;
     RT_D void push(uint32_t r, float tt) {
-        if (sp < LDS_STACK) { lref[64 * sp] = r; lt[64 * sp] = tt; }
-        else { oref[sp - LDS_STACK] = r; ot[sp - LDS_STACK] = tt; }
+        unsigned long long e = ((unsigned long long)__float_as_uint(tt) << 32) | r;
+        if (sp < LDS_STACK) lds[64 * sp] = e;
+        else ovf[64 * (sp - LDS_STACK)] = e;
         ++sp;
     }
     RT_D bool pop(uint32_t& r, float& tt) {
         if (sp == 0) return false;
         --sp;
-        if (sp < LDS_STACK) { r = lref[64 * sp]; tt = lt[64 * sp]; }
-        else { r = oref[sp - LDS_STACK]; tt = ot[sp - LDS_STACK]; }
+        unsigned long long e;
+        if (sp < LDS_STACK) e = lds[64 * sp];
+        else e = ovf[64 * (sp - LDS_STACK)];
+        r = (uint32_t)e;
+        tt = __uint_as_float((uint32_t)(e >> 32));
         return true;
     }
 };
@@ -283,8 +333,8 @@ RT_D uint32_t node_step(const DScene& sc, const TravRay& r, uint32_t cur, float 
 }
 
 // One leaf: primitive or medium test; a hit shrinks tmax.  Returns the next reference.
-template <bool COUNT, class Stack>
-RT_D uint32_t leaf_step(const DScene& sc, const TravRay& r, uint32_t cur, float& tmax, uint32_t& best, const MediumKey& key, Stack& st,
+template <bool COUNT, class Stack, class Key>
+RT_D uint32_t leaf_step(const DScene& sc, const TravRay& r, uint32_t cur, float& tmax, uint32_t& best, const Key& key, Stack& st,
                         Probe& pr) {
     float t;
     bool hit;
@@ -300,8 +350,8 @@ RT_D uint32_t leaf_step(const DScene& sc, const TravRay& r, uint32_t cur, float&
 // Leaves whose boxes span (almost) the whole scene are kept out of the tree and tested first,
 // by every lane at once.  A sphere still passes through the reference's box test of that leaf
 // (AABB::from_points(c - r, c + r), src/hittable.rs:160-163) before Sphere::hit is evaluated.
-template <bool COUNT>
-RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_t& best, const MediumKey& key, Probe& pr) {
+template <bool COUNT, class Key>
+RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_t& best, const Key& key, Probe& pr) {
     for (uint32_t g = 0; g < sc.n_global; ++g) {
         uint32_t ref = sc.global_refs[g];
         float t;
@@ -743,9 +793,9 @@ static constexpr int INNER_MIN = 20;
 template <bool COUNT>
 __global__ __launch_bounds__(EXTEND_BLOCK) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                          const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
-                                                         const float4* __restrict__ ray_d, uint2* __restrict__ hits, DCounters* counters) {
-    __shared__ uint32_t s_ref[EXTEND_BLOCK / 64][LDS_STACK][64];
-    __shared__ float s_t[EXTEND_BLOCK / 64][LDS_STACK][64];
+                                                         const float4* __restrict__ ray_d, uint2* __restrict__ hits,
+                                                         unsigned long long* __restrict__ stack_overflow, DCounters* counters) {
+    __shared__ unsigned long long s_stack[EXTEND_BLOCK / 64][LDS_STACK][64];
     const uint32_t n = counts[bounce];
     const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
     const uint32_t wave = blockIdx.x * (EXTEND_BLOCK / 64) + wave_in_block, n_waves = gridDim.x * (EXTEND_BLOCK / 64);
@@ -757,9 +807,9 @@ __global__ __launch_bounds__(EXTEND_BLOCK) void k_extend(DScene sc, BatchInfo b,
     uint32_t next = blk * 64u;
     uint32_t blk_end = min(n, next + 64u);
 
-    LdsStack st;
-    st.lref = &s_ref[wave_in_block][0][lane];
-    st.lt = &s_t[wave_in_block][0][lane];
+    WaveStack st;
+    st.lds = (lds_u64*)&s_stack[wave_in_block][0][lane];
+    st.ovf = (global_u64*)(stack_overflow + ((size_t)wave * OVERFLOW_STACK) * 64 + lane);
     Probe pr;
     uint32_t segs = 0, nhit = 0;
 
@@ -767,8 +817,9 @@ __global__ __launch_bounds__(EXTEND_BLOCK) void k_extend(DScene sc, BatchInfo b,
     uint32_t cur = REF_DONE, best = REF_NONE;
     float tmax = RT_INF;
     TravRay r;
-    MediumKey key{seed, 0, 0, bounce};
+    BatchMediumKey key{seed, 0, bounce, b};
     const uint32_t root = sc.root == REF_NONE ? REF_DONE : sc.root;
+    const bool first_leaves_done = sc.n_global != 0;  // k_first_leaves has run: hits[] holds each ray's starting (tmax, leaf)
 
     for (;;) {
         // retire finished rays, hand out new ones
@@ -791,15 +842,16 @@ __global__ __launch_bounds__(EXTEND_BLOCK) void k_extend(DScene sc, BatchInfo b,
                 if (mine == REF_NONE && rank < avail) {
                     mine = next + rank;
                     float4 ro = ray_o[mine], rd = ray_d[mine];
-                    uint32_t path = __float_as_uint(rd.w);
-                    uint32_t s_local = path / b.n_pixels;
-                    key.pixel = b.first_pixel + (path - s_local * b.n_pixels);
-                    key.sample = b.first_sample + s_local;
+                    key.path = __float_as_uint(rd.w);
                     r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
                     tmax = RT_INF;
                     best = REF_NONE;
+                    if (first_leaves_done) {
+                        uint2 h0 = hits[mine];
+                        tmax = __uint_as_float(h0.x);
+                        best = h0.y;
+                    }
                     st.sp = 0;
-                    global_leaves<COUNT>(sc, r, tmax, best, key, pr);
                     cur = root;
                 }
                 next += min((uint32_t)__popcll(idle), avail);
@@ -819,6 +871,26 @@ __global__ __launch_bounds__(EXTEND_BLOCK) void k_extend(DScene sc, BatchInfo b,
         if (mine != REF_NONE && cur != REF_DONE && ref_is_leaf(cur)) cur = leaf_step<COUNT>(sc, r, cur, tmax, best, key, st, pr);
     }
     if (COUNT) flush_probe(counters, pr, segs, nhit);
+}
+
+// Runs ahead of k_extend when the scene has leaves that are kept out of the tree: tests them
+// for every ray of the queue with all lanes busy, and leaves the closest hit so far in hits[].
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_first_leaves(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
+                                                      const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
+                                                      const float4* __restrict__ ray_d, uint2* __restrict__ hits, DCounters* counters) {
+    const uint32_t n = counts[bounce];
+    Probe pr;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 ro = ray_o[i], rd = ray_d[i];
+        BatchMediumKey key{seed, __float_as_uint(rd.w), bounce, b};
+        TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
+        float tmax = RT_INF;
+        uint32_t best = REF_NONE;
+        global_leaves<COUNT>(sc, r, tmax, best, key, pr);
+        hits[i] = make_uint2(__float_as_uint(tmax), best);
+    }
+    if (COUNT) flush_probe(counters, pr, 0, 0);
 }
 
 // One (ray, hit) pair through ray_colour's loop body (src/camera.rs:344-361): writes the path's
@@ -1131,12 +1203,35 @@ void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam
     hipLaunchKernelGGL(k_primary_rays, dim3(grid_for(n, max_blocks)), dim3(256), 0, st, cam, seed, sample, pixels, n, out);
 }
 
-void launch_extend(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
-                   uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits, DCounters* counters) {
-    // persistent waves: no more blocks than fit the chip at once (LDS: 32 KiB per block -> 5 per CU)
-    dim3 grid(grid_for(upper_bound, (max_blocks / 8u) * 5u));
-    if (counters) hipLaunchKernelGGL(k_extend<true>, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
-    else hipLaunchKernelGGL(k_extend<false>, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
+// Blocks of the extend kernel that one CU holds at a time, as the runtime computes it from the
+// kernel's registers, LDS and scratch.  The persistent grid must not exceed CUs x this number:
+// blocks beyond it only start when earlier ones have finished, and then work their interleaved
+// share of the queue on an almost empty chip.
+int extend_blocks_per_cu() {
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_extend<false>, EXTEND_BLOCK, 0) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_extend<true>, EXTEND_BLOCK, 0) != hipSuccess) b = 0;
+    (void)hipGetLastError();
+    // a block whose LDS divides the CU's 160 KiB exactly does not get the last slot in practice
+    int by_lds = (int)((160u * 1024u - 1024u) / sizeof(unsigned long long[EXTEND_BLOCK / 64][LDS_STACK][64]));
+    return std::min(std::min(a, b), by_lds);
+}
+// bytes of the extend kernel's stack overflow area for a grid of `blocks` blocks
+size_t extend_overflow_bytes(uint32_t blocks) { return (size_t)blocks * (EXTEND_BLOCK / 64) * OVERFLOW_STACK * 64 * sizeof(unsigned long long); }
+
+void launch_extend(hipStream_t st, uint32_t resident_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
+                   uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits,
+                   unsigned long long* stack_overflow, DCounters* counters) {
+    if (sc.n_global != 0) {
+        dim3 g0(grid_for(upper_bound, 8192));
+        if (counters) hipLaunchKernelGGL(k_first_leaves<true>, g0, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
+        else hipLaunchKernelGGL(k_first_leaves<false>, g0, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
+    }
+    dim3 grid(grid_for(upper_bound, resident_blocks));
+    if (counters)
+        hipLaunchKernelGGL(k_extend<true>, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, stack_overflow, counters);
+    else
+        hipLaunchKernelGGL(k_extend<false>, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, stack_overflow, counters);
 }
 
 void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const DCamera& cam, const BatchInfo& b,

@@ -299,6 +299,11 @@ class Scene(BuilderCalls):
         cam = self.camera_desc()
         self._check(self.amd.rt_render_accumulate_device(self.rt_scene, C.byref(cam), seed, first_sample, n_samples, d_acc))
 
+    def info(self):
+        i = _abi.RtSceneInfo()
+        self._check(self.amd.rt_scene_get_info(self.rt_scene, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in i._fields_}
+
     def synchronize(self):
         self._check(self.amd.rt_ctx_synchronize(self.ctx))
 
