@@ -38,9 +38,9 @@ FLOPS = {"node_visits": 50, "sphere_tests": 30, "quad_tests": 45, "hits": 20}
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=8)
+    p.add_argument("--steps", type=int, default=6)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--spp-per-step", type=int, default=8)
+    p.add_argument("--spp-per-step", type=int, default=16)
     p.add_argument("--width", type=int, default=WIDTH)
     p.add_argument("--height", type=int, default=HEIGHT)
     p.add_argument("--seed", type=int, default=0)

@@ -374,7 +374,8 @@ int rt_ctx_synchronize(rt_ctx* ctx);
  * timing on, every kernel launch is bracketed by an event pair;
  * rt_ctx_synchronize sums them per phase over all renders enqueued since the
  * previous rt_ctx_synchronize, and rt_ctx_phase_ms reads the sums (milliseconds,
- * number of launches).  phase: 0 raygen, 1 extend, 2 shade, 3 accumulate. */
+ * number of launches).  phase: 0 raygen, 1 extend, 2 shade, 3 accumulate,
+ * 4 the pass over the leaves kept out of the tree (part of extend). */
 int rt_ctx_last_render_ms(rt_ctx* ctx, float* total_ms);
 int rt_ctx_set_phase_timing(rt_ctx* ctx, int enabled);
 int rt_ctx_phase_ms(rt_ctx* ctx, int phase, float* ms, uint32_t* launches);

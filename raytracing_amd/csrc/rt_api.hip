@@ -43,8 +43,8 @@ int fail(int code, const char* fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                                \
     } while (0)
 
-constexpr uint64_t DEFAULT_BATCH_PATHS = 16ull << 20;
-constexpr int N_PHASES = 4;
+constexpr uint64_t DEFAULT_BATCH_PATHS = 128ull << 20;  // 124 B of queue memory per path
+constexpr int N_PHASES = 5;
 
 struct EventPair {
     hipEvent_t a, b;
@@ -58,6 +58,8 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
     uint32_t max_blocks = 2048;
     uint32_t extend_blocks = 1024;  // persistent grid of the extend kernel: what the chip holds at once
+    uint32_t extend_blocks_counting = 1024;  // the same for its counting build (more registers)
+    rt::ExtendTuning tune;
     uint64_t batch_paths = DEFAULT_BATCH_PATHS;
     bool counters_on = false;
     bool phase_timing = false;
@@ -79,8 +81,8 @@ struct rt_ctx {
     bool have_render_time = false;
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
-    float phase_ms[N_PHASES] = {0, 0, 0, 0};
-    uint32_t phase_launches[N_PHASES] = {0, 0, 0, 0};
+    float phase_ms[N_PHASES] = {};
+    uint32_t phase_launches[N_PHASES] = {};
     bool phase_pending = false;
 };
 
@@ -374,10 +376,14 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     c->device = device_id;
     c->max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
     {
-        int per_cu = rt::extend_blocks_per_cu();
+        int per_cu = rt::extend_blocks_per_cu(false), per_cu_counting = rt::extend_blocks_per_cu(true);
         if (const char* e = getenv("RT_AMD_EXTEND_BLOCKS_PER_CU")) per_cu = atoi(e);  // tuning experiments only
         if (per_cu < 1) per_cu = 4;
+        if (per_cu_counting < 1) per_cu_counting = 3;
         c->extend_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)per_cu;
+        c->extend_blocks_counting = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::min(per_cu, per_cu_counting);
+        if (const char* e = getenv("RT_AMD_EXTEND_TUNING"))  // "inner,refill,medium": tuning experiments only
+            sscanf(e, "%d,%d,%d", &c->tune.inner_min, &c->tune.refill_min, &c->tune.medium_min);
         if (getenv("RT_AMD_VERBOSE")) fprintf(stderr, "[rt_amd] extend kernel: %d blocks per CU, grid %u\n", per_cu, c->extend_blocks);
     }
     hipError_t e = hipMalloc((void**)&c->d_counters, sizeof(DCounters));
@@ -825,9 +831,21 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
     if ((e = set_device(c))) return e;
     if ((uint64_t)first_sample + n_samples > 0xFFFFFFFFull) return fail(RT_ERR_INVALID_ARGUMENT, "sample numbers overflow 32 bits");
     const uint64_t npix = (uint64_t)cam->width * cam->height;
-    const uint32_t chunk_pixels = (uint32_t)std::min<uint64_t>(npix, c->batch_paths);
+    // paths per batch: the configured number, but no more than fits the memory that is free now
+    uint64_t batch_paths = c->batch_paths;
+    {
+        constexpr uint64_t BYTES_PER_PATH = 6 * sizeof(float4) + sizeof(uint2) + sizeof(uint32_t) + sizeof(float4);
+        size_t free_b = 0, total_b = 0;
+        const uint64_t wanted = std::min<uint64_t>(batch_paths, npix * (uint64_t)n_samples);
+        if (wanted > c->queue_cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            uint64_t usable = (uint64_t)((double)free_b * 0.9) + c->queue_cap * BYTES_PER_PATH;
+            batch_paths = std::max<uint64_t>(std::min<uint64_t>(batch_paths, usable / BYTES_PER_PATH), 1u << 16);
+        }
+        (void)hipGetLastError();
+    }
+    const uint32_t chunk_pixels = (uint32_t)std::min<uint64_t>(npix, batch_paths);
     uint32_t spb = 1;  // samples per batch
-    if (chunk_pixels == npix) spb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->batch_paths / npix, n_samples));
+    if (chunk_pixels == npix) spb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(batch_paths / npix, n_samples));
     // counts[0 .. max_depth + 1]: queue lengths per bounce; counts[max_depth + 2 + bounce]: textured hits of that bounce
     const uint32_t n_queue_counts = cam->max_depth + 2;
     const uint32_t n_counts = 2 * cam->max_depth + 2;
@@ -848,8 +866,13 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
             if ((e = phase_end(c, ep))) return e;
             int cur = 0;
             for (uint32_t bounce = 0; bounce < cam->max_depth; ++bounce) {
+                if (sc->d.n_global != 0) {
+                    if ((e = phase_begin(c, 4, &ep))) return e;
+                    launch_first_leaves(c->stream, c->max_blocks, total, sc->d, b, seed, bounce, c->counts, c->ray_o[cur], c->ray_d[cur], c->hits, counters);
+                    if ((e = phase_end(c, ep))) return e;
+                }
                 if ((e = phase_begin(c, 1, &ep))) return e;
-                launch_extend(c->stream, c->extend_blocks, total, sc->d, b, seed, bounce, c->counts, c->ray_o[cur], c->ray_d[cur], c->hits, c->stack_overflow, counters);
+                launch_extend(c->stream, counters ? c->extend_blocks_counting : c->extend_blocks, total, sc->d, b, seed, bounce, c->counts, c->ray_o[cur], c->ray_d[cur], c->hits, c->stack_overflow, c->tune, counters);
                 if ((e = phase_end(c, ep))) return e;
                 if ((e = phase_begin(c, 2, &ep))) return e;
                 launch_shade(c->stream, c->max_blocks, total, sc->d, dcam, b, seed, bounce, c->counts, c->counts + n_queue_counts + bounce,

@@ -20,12 +20,21 @@ void launch_raygen(hipStream_t st, uint32_t max_blocks, const DCamera& cam, cons
                    float4* thr, uint32_t* counts, uint32_t n_counts);
 void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam, uint64_t seed, uint32_t sample, const uint32_t* pixels,
                          unsigned long long n, rt_ray* out);
-int extend_blocks_per_cu();
+// Lane-count thresholds of the extend kernel's loop (see k_extend).
+struct ExtendTuning {
+    int inner_min = 20;   // keep stepping through inner nodes while this many lanes are at one
+    int refill_min = 16;  // fetch new rays once this many lanes are free
+    int medium_min = 12;  // run the medium test once this many lanes wait at a medium
+};
+int extend_blocks_per_cu(bool counting);
 size_t extend_overflow_bytes(uint32_t blocks);
-// resident_blocks: CUs x extend_blocks_per_cu(); stack_overflow: extend_overflow_bytes(resident_blocks) bytes
+// Must run before launch_extend when sc.n_global != 0 (the extend kernel then starts every ray from hits[]).
+void launch_first_leaves(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
+                         uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits, DCounters* counters);
+// resident_blocks: CUs x extend_blocks_per_cu(counters != nullptr); stack_overflow: extend_overflow_bytes(resident_blocks) bytes
 void launch_extend(hipStream_t st, uint32_t resident_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
                    uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits,
-                   unsigned long long* stack_overflow, DCounters* counters);
+                   unsigned long long* stack_overflow, const ExtendTuning& tune, DCounters* counters);
 // counts[bounce] in, counts[bounce + 1] out; tex_count / tex_list: this bounce's list of hits on
 // textured materials (filled by the first kernel, consumed by the second).
 void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const DCamera& cam, const BatchInfo& b,

@@ -703,7 +703,11 @@ RT_D unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
-RT_D void flush_probe(DCounters* c, const Probe& pr, uint32_t segments, uint32_t hits) {
+RT_D void flush_probe(DCounters* c, const Probe& pr, uint32_t segments, uint32_t hits, uint32_t slots = 0) {
+    if (slots) {
+        unsigned long long sl = wave_sum(slots);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&c->_pad, sl);
+    }
     unsigned long long n = wave_sum(pr.nodes), s = wave_sum(pr.spheres), q = wave_sum(pr.quads), m = wave_sum(pr.media);
     unsigned long long sg = wave_sum(segments), h = wave_sum(hits);
     if ((threadIdx.x & 63) == 0) {
@@ -783,18 +787,27 @@ __global__ __launch_bounds__(256) void k_primary_rays(DCamera cam, uint64_t seed
 //
 // Persistent waves: wave w owns every n_waves-th 64-ray block of the queue and its 64 lanes
 // pull rays from them one by one, so a lane that finishes a short ray starts the next
-// instead of idling until the longest ray of a 64-ray batch is done.  Inside the loop the
-// wave alternates between an inner-node phase (run while at least INNER_MIN lanes are at inner
-// nodes, or nobody waits at a leaf) and a leaf phase, which keeps lanes that do the same kind
-// of work together.
+// instead of idling until the longest ray of a 64-ray batch is done.
+//
+// Each turn of the loop has four parts, each run by the lanes it concerns: fetching new rays
+// (once REFILL_MIN lanes are free), stepping through inner nodes (while INNER_MIN lanes are at
+// one), testing the sphere / quad leaves lanes have arrived at, and testing media.  The medium
+// test is by far the longest, so lanes that arrive at a medium wait there until MEDIUM_MIN of
+// them have gathered (or nothing else is left to do).
+#ifndef RT_LANE_STATS
+#define RT_LANE_STATS 0  // development builds: 1..6 count the lane slots of one state of k_extend in DCounters::_pad
+#endif
 static constexpr int EXTEND_BLOCK = 256;
-static constexpr int INNER_MIN = 20;
 
+#ifndef RT_EXTEND_WAVES
+#define RT_EXTEND_WAVES 6  // resident waves per SIMD the register allocation aims for
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(EXTEND_BLOCK) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
+__global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_EXTEND_WAVES, RT_EXTEND_WAVES))) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                          const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
                                                          const float4* __restrict__ ray_d, uint2* __restrict__ hits,
-                                                         unsigned long long* __restrict__ stack_overflow, DCounters* counters) {
+                                                         unsigned long long* __restrict__ stack_overflow, ExtendTuning tune,
+                                                         DCounters* counters) {
     __shared__ unsigned long long s_stack[EXTEND_BLOCK / 64][LDS_STACK][64];
     const uint32_t n = counts[bounce];
     const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
@@ -811,7 +824,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) void k_extend(DScene sc, BatchInfo b,
     st.lds = (lds_u64*)&s_stack[wave_in_block][0][lane];
     st.ovf = (global_u64*)(stack_overflow + ((size_t)wave * OVERFLOW_STACK) * 64 + lane);
     Probe pr;
-    uint32_t segs = 0, nhit = 0;
+    uint32_t segs = 0, nhit = 0, slots = 0;
 
     uint32_t mine = REF_NONE;  // queue slot this lane is working on
     uint32_t cur = REF_DONE, best = REF_NONE;
@@ -821,56 +834,114 @@ __global__ __launch_bounds__(EXTEND_BLOCK) void k_extend(DScene sc, BatchInfo b,
     const uint32_t root = sc.root == REF_NONE ? REF_DONE : sc.root;
     const bool first_leaves_done = sc.n_global != 0;  // k_first_leaves has run: hits[] holds each ray's starting (tmax, leaf)
 
+    // A turn in which no part ran (the thresholds below held every lane back) is followed by one
+    // that runs every part for whatever lanes it has, so the loop always moves on.
+    bool eager = false;
     for (;;) {
-        // retire finished rays, hand out new ones
-        if (mine != REF_NONE && cur == REF_DONE) {
+        bool moved = false;
+        const int refill_min = eager ? 1 : tune.refill_min, inner_min = eager ? 1 : tune.inner_min, medium_min = eager ? 1 : tune.medium_min;
+        if (__ballot(mine != REF_NONE && cur == REF_DONE)) moved = true;
+        if (mine != REF_NONE && cur == REF_DONE) {  // retire
             hits[mine] = make_uint2(__float_as_uint(tmax), best);
             if (COUNT) { segs++; nhit += (best != REF_NONE); }
             mine = REF_NONE;
         }
-        unsigned long long idle = __ballot(mine == REF_NONE);
-        if (idle) {
-            if (next == blk_end && next < n) {  // block used up: on to this wave's next one
-                unsigned long long nb = ((unsigned long long)blk + n_waves) * 64ull;
-                blk += n_waves;
-                next = (uint32_t)min(nb, (unsigned long long)n);
-                blk_end = (uint32_t)min(nb + 64ull, (unsigned long long)n);
-            }
-            uint32_t avail = blk_end - next;
-            if (avail) {
-                uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (mine == REF_NONE && rank < avail) {
-                    mine = next + rank;
-                    float4 ro = ray_o[mine], rd = ray_d[mine];
-                    key.path = __float_as_uint(rd.w);
-                    r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
-                    tmax = RT_INF;
-                    best = REF_NONE;
-                    if (first_leaves_done) {
-                        uint2 h0 = hits[mine];
-                        tmax = __uint_as_float(h0.x);
-                        best = h0.y;
-                    }
-                    st.sp = 0;
-                    cur = root;
-                }
-                next += min((uint32_t)__popcll(idle), avail);
-            } else if (idle == ~0ull) {
-                break;
-            }
+        if (next == blk_end && next < n) {  // block used up: on to this wave's next one
+            unsigned long long nb = ((unsigned long long)blk + n_waves) * 64ull;
+            blk += n_waves;
+            next = (uint32_t)min(nb, (unsigned long long)n);
+            blk_end = (uint32_t)min(nb + 64ull, (unsigned long long)n);
         }
-        // inner-node phase
+        const uint32_t avail = blk_end - next;
+        const unsigned long long m_idle = __ballot(mine == REF_NONE);
+        if (m_idle == ~0ull && avail == 0) break;
+        const uint32_t n_refill = min((uint32_t)__popcll(m_idle), avail);
+#if RT_LANE_STATS == 4
+        if (COUNT) slots++;
+#endif
+        // lanes with a ray never hold REF_DONE here; leaf kinds: 0, 1 spheres, 2 quads, 3 media
+        unsigned long long m_busy = __ballot(mine != REF_NONE && (cur >> 29) != 7u);  // at an inner node, a sphere or a quad
+        if (n_refill != 0 && ((int)__popcll(m_idle) >= refill_min || m_busy == 0)) {
+            moved = true;
+#if RT_LANE_STATS == 3
+            if (COUNT) slots++;
+#endif
+            uint32_t rank = (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull));
+            if (mine == REF_NONE && rank < avail) {
+                mine = next + rank;
+                float4 ro = ray_o[mine], rd = ray_d[mine];
+                key.path = __float_as_uint(rd.w);
+                r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
+                tmax = RT_INF;
+                best = REF_NONE;
+                if (first_leaves_done) {
+                    uint2 h0 = hits[mine];
+                    tmax = __uint_as_float(h0.x);
+                    best = h0.y;
+                }
+                st.sp = 0;
+                cur = root;
+            }
+            next += n_refill;
+        }
+        // inner nodes
         for (;;) {
-            bool at_inner = mine != REF_NONE && cur != REF_DONE && !ref_is_leaf(cur);
-            unsigned long long m = __ballot(at_inner);
+            const bool at_inner = mine != REF_NONE && !ref_is_leaf(cur);  // REF_DONE has the leaf bit set
+            const unsigned long long m = __ballot(at_inner);
             if (m == 0) break;
-            if (__popcll(m) < INNER_MIN && __ballot(mine != REF_NONE && cur != REF_DONE && ref_is_leaf(cur)) != 0) break;
+            if ((int)__popcll(m) < inner_min) {
+                const bool parked = mine != REF_NONE && cur != REF_DONE && ref_is_leaf(cur);
+                const unsigned long long m_prim = __ballot(parked && ref_kind(cur) != KIND_MEDIUM);
+                const unsigned long long m_med = __ballot(parked && ref_kind(cur) == KIND_MEDIUM);
+                if (m_prim != 0 || (int)__popcll(m_med) >= medium_min) break;
+                if (next < n && (int)__popcll(__ballot(mine == REF_NONE || cur == REF_DONE)) >= refill_min) break;
+            }
+            moved = true;
+#if RT_LANE_STATS == 1
+            if (COUNT) slots++;
+#endif
             if (at_inner) cur = node_step<COUNT>(sc, r, cur, tmax, st, pr);
         }
-        // leaf phase
-        if (mine != REF_NONE && cur != REF_DONE && ref_is_leaf(cur)) cur = leaf_step<COUNT>(sc, r, cur, tmax, best, key, st, pr);
+        // sphere and quad leaves
+        {
+            const bool at_prim = mine != REF_NONE && cur != REF_DONE && ref_is_leaf(cur) && ref_kind(cur) != KIND_MEDIUM;
+#if RT_LANE_STATS == 2
+            if (COUNT && __ballot(at_prim)) slots++;
+#endif
+            if (__ballot(at_prim)) moved = true;
+            if (at_prim) {
+                float t;
+                if (leaf_root<COUNT>(sc, cur, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr)) { tmax = t; best = cur; }
+                cur = pop_next(st, tmax);
+            }
+        }
+        // media: once enough lanes wait at one, or when the wave has nothing else it could do
+        {
+            const bool at_medium = mine != REF_NONE && cur != REF_DONE && ref_is_leaf(cur) && ref_kind(cur) == KIND_MEDIUM;
+            const unsigned long long m_med = __ballot(at_medium);
+            if (m_med != 0) {
+                bool run = (int)__popcll(m_med) >= medium_min;
+                if (!run) {
+                    const unsigned long long m_other = __ballot(mine != REF_NONE && !at_medium);  // includes finished rays: they free lanes
+                    const bool can_refill = avail > n_refill || (__ballot(mine == REF_NONE) != 0 && next < n);
+                    run = m_other == 0 && !can_refill;
+                }
+                if (run) {
+                    moved = true;
+#if RT_LANE_STATS == 6
+                    if (COUNT) slots++;
+#endif
+                    if (at_medium) {
+                        float t;
+                        if (medium_root<COUNT>(sc, ref_index(cur), r.o, r.d, r.time, r.a, r.tmin, tmax, key, t, pr)) { tmax = t; best = cur; }
+                        cur = pop_next(st, tmax);
+                    }
+                }
+            }
+        }
+        eager = !moved;
     }
-    if (COUNT) flush_probe(counters, pr, segs, nhit);
+    if (COUNT) flush_probe(counters, pr, segs, nhit, slots);
 }
 
 // Runs ahead of k_extend when the scene has leaves that are kept out of the tree: tests them
@@ -1203,35 +1274,38 @@ void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam
     hipLaunchKernelGGL(k_primary_rays, dim3(grid_for(n, max_blocks)), dim3(256), 0, st, cam, seed, sample, pixels, n, out);
 }
 
-// Blocks of the extend kernel that one CU holds at a time, as the runtime computes it from the
+// Blocks of the extend kernel (plain or counting build) that one CU holds at a time, as the runtime computes it from the
 // kernel's registers, LDS and scratch.  The persistent grid must not exceed CUs x this number:
 // blocks beyond it only start when earlier ones have finished, and then work their interleaved
 // share of the queue on an almost empty chip.
-int extend_blocks_per_cu() {
-    int a = 0, b = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_extend<false>, EXTEND_BLOCK, 0) != hipSuccess) a = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_extend<true>, EXTEND_BLOCK, 0) != hipSuccess) b = 0;
+int extend_blocks_per_cu(bool counting) {
+    int a = 0;
+    hipError_t e = counting ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_extend<true>, EXTEND_BLOCK, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_extend<false>, EXTEND_BLOCK, 0);
+    if (e != hipSuccess) a = 0;
     (void)hipGetLastError();
     // a block whose LDS divides the CU's 160 KiB exactly does not get the last slot in practice
     int by_lds = (int)((160u * 1024u - 1024u) / sizeof(unsigned long long[EXTEND_BLOCK / 64][LDS_STACK][64]));
-    return std::min(std::min(a, b), by_lds);
+    return std::min(a, by_lds);
 }
 // bytes of the extend kernel's stack overflow area for a grid of `blocks` blocks
 size_t extend_overflow_bytes(uint32_t blocks) { return (size_t)blocks * (EXTEND_BLOCK / 64) * OVERFLOW_STACK * 64 * sizeof(unsigned long long); }
 
+void launch_first_leaves(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
+                         uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits, DCounters* counters) {
+    dim3 g0(grid_for(upper_bound, max_blocks * 4u));
+    if (counters) hipLaunchKernelGGL(k_first_leaves<true>, g0, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
+    else hipLaunchKernelGGL(k_first_leaves<false>, g0, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
+}
+
 void launch_extend(hipStream_t st, uint32_t resident_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
                    uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits,
-                   unsigned long long* stack_overflow, DCounters* counters) {
-    if (sc.n_global != 0) {
-        dim3 g0(grid_for(upper_bound, 8192));
-        if (counters) hipLaunchKernelGGL(k_first_leaves<true>, g0, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
-        else hipLaunchKernelGGL(k_first_leaves<false>, g0, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
-    }
+                   unsigned long long* stack_overflow, const ExtendTuning& tune, DCounters* counters) {
     dim3 grid(grid_for(upper_bound, resident_blocks));
     if (counters)
-        hipLaunchKernelGGL(k_extend<true>, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, stack_overflow, counters);
+        hipLaunchKernelGGL(k_extend<true>, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, stack_overflow, tune, counters);
     else
-        hipLaunchKernelGGL(k_extend<false>, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, stack_overflow, counters);
+        hipLaunchKernelGGL(k_extend<false>, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, stack_overflow, tune, counters);
 }
 
 void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const DCamera& cam, const BatchInfo& b,

@@ -332,7 +332,7 @@ class Scene(BuilderCalls):
     def phase_ms(self):
         """{phase: (milliseconds, launches)} of the last synchronized render."""
         out = {}
-        for i, name in enumerate(["raygen", "extend", "shade", "accumulate"]):
+        for i, name in enumerate(["raygen", "extend", "shade", "accumulate", "first_leaves"]):
             ms, n = C.c_float(), C.c_uint32()
             self._check(self.amd.rt_ctx_phase_ms(self.ctx, i, C.byref(ms), C.byref(n)))
             out[name] = (ms.value, int(n.value))
