@@ -97,6 +97,7 @@ RT_ABI = {
     "rt_ctx_destroy": (C.c_int, [_P]),
     "rt_ctx_set_stream": (C.c_int, [_P, _P]),
     "rt_ctx_set_batch_paths": (C.c_int, [_P, _U64]),
+    "rt_ctx_set_pipelines": (C.c_int, [_P, C.c_int]),
     "rt_ctx_set_counters": (C.c_int, [_P, C.c_int]),
     "rt_ctx_get_counters": (C.c_int, [_P, C.POINTER(RtCounters), C.c_int]),
     "rt_buffer_create": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),

@@ -51,6 +51,27 @@ struct EventPair {
     int phase;
 };
 
+constexpr int MAX_PIPES = 2;
+constexpr uint64_t BYTES_PER_PATH = 6 * sizeof(float4) + sizeof(uint2) + sizeof(uint32_t) + sizeof(float4);
+
+// Everything one batch in flight needs: the ray / throughput queues (double-buffered), hit
+// records, the list of textured hits, per-path radiance, queue counters, and the extend
+// kernel's stack overflow area.
+struct Pipe {
+    hipStream_t stream = nullptr;  // pipe 0 of a one-pipe context runs on the caller's stream instead
+    uint64_t cap = 0;              // paths the queues hold
+    float4* ray_o[2] = {nullptr, nullptr};
+    float4* ray_d[2] = {nullptr, nullptr};
+    float4* thr[2] = {nullptr, nullptr};
+    uint2* hits = nullptr;
+    uint32_t* tex_list = nullptr;
+    float4* radiance = nullptr;
+    uint32_t* counts = nullptr;
+    uint32_t counts_cap = 0;
+    unsigned long long* stack_overflow = nullptr;
+    hipEvent_t done = nullptr;     // accumulate of the pipe's latest batch
+};
+
 }  // namespace
 
 struct rt_ctx {
@@ -64,18 +85,12 @@ struct rt_ctx {
     bool counters_on = false;
     bool phase_timing = false;
 
-    // queues (capacity = queue_cap paths)
-    uint64_t queue_cap = 0;
-    float4* ray_o[2] = {nullptr, nullptr};
-    float4* ray_d[2] = {nullptr, nullptr};
-    float4* thr[2] = {nullptr, nullptr};
-    uint2* hits = nullptr;
-    uint32_t* tex_list = nullptr;
-    float4* radiance = nullptr;
-    uint32_t* counts = nullptr;
-    uint32_t counts_cap = 0;
+    // Batches of one render call are dealt to n_pipes pipelines in turn.  With two, the kernels of
+    // consecutive batches overlap on the chip: the extend kernel is bound by instruction issue
+    // and latency, ray generation / shade / accumulate by HBM.
+    int n_pipes = 2;
+    Pipe pipes[MAX_PIPES];
     DCounters* d_counters = nullptr;
-    unsigned long long* stack_overflow = nullptr;  // deep stack levels of the extend kernel's resident waves
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool have_render_time = false;
@@ -102,46 +117,59 @@ int set_device(const rt_ctx* ctx) {
     return RT_OK;
 }
 
-void free_queues(rt_ctx* c) {
+void free_queues(Pipe& p) {
     for (int i = 0; i < 2; ++i) {
-        if (c->ray_o[i]) (void)hipFree(c->ray_o[i]);
-        if (c->ray_d[i]) (void)hipFree(c->ray_d[i]);
-        if (c->thr[i]) (void)hipFree(c->thr[i]);
-        c->ray_o[i] = c->ray_d[i] = c->thr[i] = nullptr;
+        if (p.ray_o[i]) (void)hipFree(p.ray_o[i]);
+        if (p.ray_d[i]) (void)hipFree(p.ray_d[i]);
+        if (p.thr[i]) (void)hipFree(p.thr[i]);
+        p.ray_o[i] = p.ray_d[i] = p.thr[i] = nullptr;
     }
-    if (c->hits) (void)hipFree(c->hits);
-    if (c->tex_list) (void)hipFree(c->tex_list);
-    if (c->radiance) (void)hipFree(c->radiance);
-    c->hits = nullptr;
-    c->tex_list = nullptr;
-    c->radiance = nullptr;
-    c->queue_cap = 0;
+    if (p.hits) (void)hipFree(p.hits);
+    if (p.tex_list) (void)hipFree(p.tex_list);
+    if (p.radiance) (void)hipFree(p.radiance);
+    p.hits = nullptr;
+    p.tex_list = nullptr;
+    p.radiance = nullptr;
+    p.cap = 0;
 }
 
-int ensure_queues(rt_ctx* c, uint64_t paths, uint32_t n_counts) {
-    if (paths > c->queue_cap) {
-        free_queues(c);
+int ensure_queues(rt_ctx* c, Pipe& p, uint64_t paths, uint32_t n_counts) {
+    if (paths > p.cap) {
+        free_queues(p);
         for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipMalloc((void**)&c->ray_o[i], paths * sizeof(float4)));
-            HIP_TRY(hipMalloc((void**)&c->ray_d[i], paths * sizeof(float4)));
-            HIP_TRY(hipMalloc((void**)&c->thr[i], paths * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&p.ray_o[i], paths * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&p.ray_d[i], paths * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&p.thr[i], paths * sizeof(float4)));
         }
-        HIP_TRY(hipMalloc((void**)&c->hits, paths * sizeof(uint2)));
-        HIP_TRY(hipMalloc((void**)&c->tex_list, paths * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&c->radiance, paths * sizeof(float4)));
-        c->queue_cap = paths;
+        HIP_TRY(hipMalloc((void**)&p.hits, paths * sizeof(uint2)));
+        HIP_TRY(hipMalloc((void**)&p.tex_list, paths * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&p.radiance, paths * sizeof(float4)));
+        p.cap = paths;
     }
-    if (n_counts > c->counts_cap) {
-        if (c->counts) (void)hipFree(c->counts);
-        c->counts = nullptr;
-        HIP_TRY(hipMalloc((void**)&c->counts, n_counts * sizeof(uint32_t)));
-        c->counts_cap = n_counts;
+    if (n_counts > p.counts_cap) {
+        if (p.counts) (void)hipFree(p.counts);
+        p.counts = nullptr;
+        HIP_TRY(hipMalloc((void**)&p.counts, n_counts * sizeof(uint32_t)));
+        p.counts_cap = n_counts;
     }
+    if (!p.stack_overflow) HIP_TRY(hipMalloc((void**)&p.stack_overflow, rt::extend_overflow_bytes(c->extend_blocks)));
+    if (!p.done) HIP_TRY(hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
+    if (!p.stream && c->n_pipes > 1) HIP_TRY(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     return RT_OK;
 }
 
+void destroy_pipe(Pipe& p) {
+    if (p.stream) (void)hipStreamSynchronize(p.stream);
+    free_queues(p);
+    if (p.counts) (void)hipFree(p.counts);
+    if (p.stack_overflow) (void)hipFree(p.stack_overflow);
+    if (p.done) (void)hipEventDestroy(p.done);
+    if (p.stream) (void)hipStreamDestroy(p.stream);
+    p = Pipe{};
+}
+
 // ---- per-launch phase timing ------------------------------------------------------
-int phase_begin(rt_ctx* c, int phase, EventPair** out) {
+int phase_begin(rt_ctx* c, hipStream_t stream, int phase, EventPair** out) {
     *out = nullptr;
     if (!c->phase_timing) return RT_OK;
     if (c->ev_used == c->ev_pool.size()) {
@@ -152,12 +180,12 @@ int phase_begin(rt_ctx* c, int phase, EventPair** out) {
     }
     EventPair* p = &c->ev_pool[c->ev_used++];
     p->phase = phase;
-    HIP_TRY(hipEventRecord(p->a, c->stream));
+    HIP_TRY(hipEventRecord(p->a, stream));
     *out = p;
     return RT_OK;
 }
-int phase_end(rt_ctx* c, EventPair* p) {
-    if (p) HIP_TRY(hipEventRecord(p->b, c->stream));
+int phase_end(hipStream_t stream, EventPair* p) {
+    if (p) HIP_TRY(hipEventRecord(p->b, stream));
     return RT_OK;
 }
 int collect_phases(rt_ctx* c) {
@@ -384,11 +412,12 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         c->extend_blocks_counting = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::min(per_cu, per_cu_counting);
         if (const char* e = getenv("RT_AMD_EXTEND_TUNING"))  // "inner,refill,medium": tuning experiments only
             sscanf(e, "%d,%d,%d", &c->tune.inner_min, &c->tune.refill_min, &c->tune.medium_min);
-        if (getenv("RT_AMD_VERBOSE")) fprintf(stderr, "[rt_amd] extend kernel: %d blocks per CU, grid %u\n", per_cu, c->extend_blocks);
+        if (const char* e = getenv("RT_AMD_PIPES")) c->n_pipes = std::min(MAX_PIPES, std::max(1, atoi(e)));  // A/B experiments only
+        if (getenv("RT_AMD_VERBOSE"))
+            fprintf(stderr, "[rt_amd] extend kernel: %d blocks per CU, grid %u; %d pipeline(s)\n", per_cu, c->extend_blocks, c->n_pipes);
     }
     hipError_t e = hipMalloc((void**)&c->d_counters, sizeof(DCounters));
     if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(DCounters));
-    if (e == hipSuccess) e = hipMalloc((void**)&c->stack_overflow, rt::extend_overflow_bytes(c->extend_blocks));
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
     if (e != hipSuccess) {
@@ -403,10 +432,8 @@ int rt_ctx_destroy(rt_ctx* c) {
     if (!c) return RT_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    free_queues(c);
-    if (c->counts) (void)hipFree(c->counts);
+    for (Pipe& p : c->pipes) destroy_pipe(p);
     if (c->d_counters) (void)hipFree(c->d_counters);
-    if (c->stack_overflow) (void)hipFree(c->stack_overflow);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -425,6 +452,13 @@ int rt_ctx_set_batch_paths(rt_ctx* c, uint64_t n) {
     if (n != 0 && n < 64) return fail(RT_ERR_INVALID_ARGUMENT, "batch of %llu paths is below one wavefront", (unsigned long long)n);
     if (n >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "batch above 2^31 paths");
     c->batch_paths = n ? n : DEFAULT_BATCH_PATHS;
+    return RT_OK;
+}
+
+int rt_ctx_set_pipelines(rt_ctx* c, int n) {
+    if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (n < 1 || n > MAX_PIPES) return fail(RT_ERR_INVALID_ARGUMENT, "%d pipelines: 1 to %d are supported", n, MAX_PIPES);
+    c->n_pipes = n;
     return RT_OK;
 }
 
@@ -831,62 +865,84 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
     if ((e = set_device(c))) return e;
     if ((uint64_t)first_sample + n_samples > 0xFFFFFFFFull) return fail(RT_ERR_INVALID_ARGUMENT, "sample numbers overflow 32 bits");
     const uint64_t npix = (uint64_t)cam->width * cam->height;
+    const uint64_t all_paths = npix * (uint64_t)n_samples;
+    // one pipeline for small jobs (and for single-sample calls, which are not split)
+    const int n_pipes = (c->n_pipes > 1 && n_samples >= 2 && all_paths >= (1ull << 22)) ? c->n_pipes : 1;
     // paths per batch: the configured number, but no more than fits the memory that is free now
     uint64_t batch_paths = c->batch_paths;
     {
-        constexpr uint64_t BYTES_PER_PATH = 6 * sizeof(float4) + sizeof(uint2) + sizeof(uint32_t) + sizeof(float4);
+        uint64_t have = 0;
+        for (int i = 0; i < n_pipes; ++i) have += c->pipes[i].cap;
+        const uint64_t wanted = std::min<uint64_t>(batch_paths * n_pipes, all_paths);
         size_t free_b = 0, total_b = 0;
-        const uint64_t wanted = std::min<uint64_t>(batch_paths, npix * (uint64_t)n_samples);
-        if (wanted > c->queue_cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            uint64_t usable = (uint64_t)((double)free_b * 0.9) + c->queue_cap * BYTES_PER_PATH;
-            batch_paths = std::max<uint64_t>(std::min<uint64_t>(batch_paths, usable / BYTES_PER_PATH), 1u << 16);
+        if (wanted > have && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            uint64_t usable = (uint64_t)((double)free_b * 0.9) + have * BYTES_PER_PATH;
+            batch_paths = std::max<uint64_t>(std::min<uint64_t>(batch_paths, usable / BYTES_PER_PATH / n_pipes), 1u << 16);
         }
         (void)hipGetLastError();
     }
     const uint32_t chunk_pixels = (uint32_t)std::min<uint64_t>(npix, batch_paths);
     uint32_t spb = 1;  // samples per batch
-    if (chunk_pixels == npix) spb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(batch_paths / npix, n_samples));
+    if (chunk_pixels == npix) {
+        spb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(batch_paths / npix, n_samples));
+        if (n_pipes > 1) spb = std::min(spb, (n_samples + (uint32_t)n_pipes - 1) / (uint32_t)n_pipes);  // at least one batch per pipeline
+    }
     // counts[0 .. max_depth + 1]: queue lengths per bounce; counts[max_depth + 2 + bounce]: textured hits of that bounce
     const uint32_t n_queue_counts = cam->max_depth + 2;
     const uint32_t n_counts = 2 * cam->max_depth + 2;
-    if ((e = ensure_queues(c, (uint64_t)chunk_pixels * spb, n_counts))) return e;
+    for (int i = 0; i < n_pipes; ++i)
+        if ((e = ensure_queues(c, c->pipes[i], (uint64_t)chunk_pixels * spb, n_counts))) return e;
     DCamera dcam = to_dcamera(cam);
     DCounters* counters = c->counters_on ? c->d_counters : nullptr;
 
     HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
+    if (n_pipes > 1)
+        for (int i = 0; i < n_pipes; ++i) HIP_TRY(hipStreamWaitEvent(c->pipes[i].stream, c->ev_begin, 0));
+    uint32_t batch_no = 0;
+    Pipe* prev = nullptr;
     for (uint64_t p0 = 0; p0 < npix; p0 += chunk_pixels) {
         const uint32_t np = (uint32_t)std::min<uint64_t>(chunk_pixels, npix - p0);
-        for (uint32_t s0 = 0; s0 < n_samples; s0 += spb) {
+        for (uint32_t s0 = 0; s0 < n_samples; s0 += spb, ++batch_no) {
             const uint32_t ns = std::min(spb, n_samples - s0);
             BatchInfo b{(uint32_t)p0, np, first_sample + s0, ns};
             const uint32_t total = np * ns;
+            Pipe& q = c->pipes[batch_no % (uint32_t)n_pipes];
+            hipStream_t st = n_pipes > 1 ? q.stream : c->stream;
             EventPair* ep;
-            if ((e = phase_begin(c, 0, &ep))) return e;
-            launch_raygen(c->stream, c->max_blocks, dcam, b, seed, c->ray_o[0], c->ray_d[0], c->thr[0], c->counts, n_counts);
-            if ((e = phase_end(c, ep))) return e;
+            if ((e = phase_begin(c, st, 0, &ep))) return e;
+            launch_raygen(st, c->max_blocks, dcam, b, seed, q.ray_o[0], q.ray_d[0], q.thr[0], q.counts, n_counts);
+            if ((e = phase_end(st, ep))) return e;
             int cur = 0;
             for (uint32_t bounce = 0; bounce < cam->max_depth; ++bounce) {
                 if (sc->d.n_global != 0) {
-                    if ((e = phase_begin(c, 4, &ep))) return e;
-                    launch_first_leaves(c->stream, c->max_blocks, total, sc->d, b, seed, bounce, c->counts, c->ray_o[cur], c->ray_d[cur], c->hits, counters);
-                    if ((e = phase_end(c, ep))) return e;
+                    if ((e = phase_begin(c, st, 4, &ep))) return e;
+                    launch_first_leaves(st, c->max_blocks, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur], q.ray_d[cur], q.hits, counters);
+                    if ((e = phase_end(st, ep))) return e;
                 }
-                if ((e = phase_begin(c, 1, &ep))) return e;
-                launch_extend(c->stream, counters ? c->extend_blocks_counting : c->extend_blocks, total, sc->d, b, seed, bounce, c->counts, c->ray_o[cur], c->ray_d[cur], c->hits, c->stack_overflow, c->tune, counters);
-                if ((e = phase_end(c, ep))) return e;
-                if ((e = phase_begin(c, 2, &ep))) return e;
-                launch_shade(c->stream, c->max_blocks, total, sc->d, dcam, b, seed, bounce, c->counts, c->counts + n_queue_counts + bounce,
-                             c->tex_list, c->ray_o[cur], c->ray_d[cur], c->thr[cur], c->hits, c->ray_o[cur ^ 1], c->ray_d[cur ^ 1],
-                             c->thr[cur ^ 1], c->radiance, sc->has_textures);
-                if ((e = phase_end(c, ep))) return e;
+                if ((e = phase_begin(c, st, 1, &ep))) return e;
+                launch_extend(st, counters ? c->extend_blocks_counting : c->extend_blocks, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur],
+                              q.ray_d[cur], q.hits, q.stack_overflow, c->tune, counters);
+                if ((e = phase_end(st, ep))) return e;
+                if ((e = phase_begin(c, st, 2, &ep))) return e;
+                launch_shade(st, c->max_blocks, total, sc->d, dcam, b, seed, bounce, q.counts, q.counts + n_queue_counts + bounce, q.tex_list,
+                             q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.hits, q.ray_o[cur ^ 1], q.ray_d[cur ^ 1], q.thr[cur ^ 1], q.radiance,
+                             sc->has_textures);
+                if ((e = phase_end(st, ep))) return e;
                 cur ^= 1;
             }
-            if (cam->max_depth == 0) HIP_TRY(hipMemsetAsync(c->radiance, 0, (size_t)total * sizeof(float4), c->stream));
-            if ((e = phase_begin(c, 3, &ep))) return e;
-            launch_accumulate(c->stream, c->max_blocks, b, c->radiance, (float4*)d_acc);
-            if ((e = phase_end(c, ep))) return e;
+            if (cam->max_depth == 0) HIP_TRY(hipMemsetAsync(q.radiance, 0, (size_t)total * sizeof(float4), st));
+            // the accumulation buffer takes the batches in their order: sample sums stay bit-identical
+            // to a one-pipeline render
+            if (n_pipes > 1 && prev && prev != &q) HIP_TRY(hipStreamWaitEvent(st, prev->done, 0));
+            if ((e = phase_begin(c, st, 3, &ep))) return e;
+            launch_accumulate(st, c->max_blocks, b, q.radiance, (float4*)d_acc);
+            if ((e = phase_end(st, ep))) return e;
+            if (n_pipes > 1) HIP_TRY(hipEventRecord(q.done, st));
+            prev = &q;
         }
     }
+    if (n_pipes > 1)
+        for (int i = 0; i < n_pipes && i < (int)batch_no; ++i) HIP_TRY(hipStreamWaitEvent(c->stream, c->pipes[i].done, 0));
     HIP_TRY(hipEventRecord(c->ev_end, c->stream));
     HIP_TRY(hipGetLastError());
     c->have_render_time = true;

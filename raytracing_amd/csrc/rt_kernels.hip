@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "rt_device.h"
 #include "rt_kernels.h"
@@ -1111,6 +1112,67 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
     }
 }
 
+// A/B variant of k_shade without the sort by class: every thread shades the queue slot it loads.
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade_unsorted(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce,
+                                                                uint32_t* __restrict__ counts, uint32_t* __restrict__ tex_count,
+                                                                uint32_t* __restrict__ tex_list, const float4* __restrict__ ray_o,
+                                                                const float4* __restrict__ ray_d, const float4* __restrict__ thr,
+                                                                const uint2* __restrict__ hits, float4* __restrict__ out_o,
+                                                                float4* __restrict__ out_d, float4* __restrict__ out_thr,
+                                                                float4* __restrict__ radiance) {
+    __shared__ float4 s_out[3][SHADE_TILE];
+    __shared__ uint32_t s_tex[SHADE_TILE];
+    __shared__ uint32_t s_alive, s_ntex, s_base, s_tex_base;
+    const uint32_t n = counts[bounce];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t tile = blockIdx.x * SHADE_TILE; tile < n; tile += gridDim.x * SHADE_TILE) {
+        if (tid == 0) { s_alive = 0; s_ntex = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SHADE_PER_THREAD; ++k) {
+            const uint32_t i = tile + k * SHADE_BLOCK + tid;
+            bool alive = false, textured = false;
+            float4 no, nd, nt;
+            if (i < n) {
+                uint2 h = hits[i];
+                textured = h.y != REF_NONE && (leaf_meta(sc, h.y)->w & 0xFFu) == CLS_TEXTURED;
+                if (!textured) alive = shade_one<false>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], thr[i], h, radiance, no, nd, nt);
+            }
+            unsigned long long mask = __ballot(alive), tmask = __ballot(textured);
+            if (mask) {
+                uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u, slot0 = 0;
+                if (lane == leader) slot0 = atomicAdd(&s_alive, (uint32_t)__popcll(mask));
+                slot0 = __shfl(slot0, (int)leader, 64);
+                if (alive) {
+                    uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                    s_out[0][slot] = no;
+                    s_out[1][slot] = nd;
+                    s_out[2][slot] = nt;
+                }
+            }
+            if (tmask) {
+                uint32_t leader = (uint32_t)__ffsll((long long)tmask) - 1u, slot0 = 0;
+                if (lane == leader) slot0 = atomicAdd(&s_ntex, (uint32_t)__popcll(tmask));
+                slot0 = __shfl(slot0, (int)leader, 64);
+                if (textured) s_tex[slot0 + (uint32_t)__popcll(tmask & ((1ull << lane) - 1ull))] = i;
+            }
+        }
+        __syncthreads();
+        const uint32_t n_alive = s_alive, n_tex = s_ntex;
+        if (tid == 0 && n_alive) s_base = atomicAdd(&counts[bounce + 1], n_alive);
+        if (tid == 64 && n_tex) s_tex_base = atomicAdd(tex_count, n_tex);
+        __syncthreads();
+        const uint32_t base = s_base, tbase = s_tex_base;
+        for (uint32_t j = tid; j < n_alive; j += SHADE_BLOCK) {
+            out_o[base + j] = s_out[0][j];
+            out_d[base + j] = s_out[1][j];
+            out_thr[base + j] = s_out[2][j];
+        }
+        for (uint32_t j = tid; j < n_tex; j += SHADE_BLOCK) tex_list[tbase + j] = s_tex[j];
+        __syncthreads();
+    }
+}
+
 // The hits k_shade set aside: materials with checker, image or perlin-noise textures.  One global
 // atomic per block appends the block's survivors.
 __global__ __launch_bounds__(256) void k_shade_textured(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce,
@@ -1314,6 +1376,11 @@ void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, con
                   bool scene_has_textures) {
     unsigned long long tiles = ((unsigned long long)upper_bound + SHADE_TILE - 1) / SHADE_TILE;
     uint32_t grid = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(tiles, 1), max_blocks);
+    static const bool unsorted = getenv("RT_AMD_SHADE_UNSORTED") != nullptr;  // A/B experiment
+    if (unsorted)
+        hipLaunchKernelGGL(k_shade_unsorted, dim3(grid), dim3(SHADE_BLOCK), 0, st, sc, cam, b, seed, bounce, counts, tex_count, tex_list, ray_o,
+                           ray_d, thr, hits, out_o, out_d, out_thr, radiance);
+    else
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, st, sc, cam, b, seed, bounce, counts, tex_count, tex_list, ray_o, ray_d, thr,
                        hits, out_o, out_d, out_thr, radiance);
     if (scene_has_textures)

@@ -313,6 +313,9 @@ class Scene(BuilderCalls):
     def set_batch_paths(self, n):
         self._check(self.amd.rt_ctx_set_batch_paths(self.ctx, n))
 
+    def set_pipelines(self, n):
+        self._check(self.amd.rt_ctx_set_pipelines(self.ctx, n))
+
     def set_counters(self, on):
         self._check(self.amd.rt_ctx_set_counters(self.ctx, int(on)))
 

@@ -233,6 +233,26 @@ def test_render_is_independent_of_batching_and_sample_splits():
     assert np.array_equal(host[..., :3], whole[..., :3]) and (host[..., 3] == 7.0).all()
 
 
+def test_two_pipelines_give_the_same_image_as_one():
+    """A render large enough to be split over the two internal streams (>= 4 Mi paths) equals the
+    one-stream render bit for bit, also when the sample count does not divide evenly."""
+    w, h, spp = 1024, 832, 5
+    one = rt.Scene.builtin(6, w, h)
+    one.set_pipelines(1)
+    one.render_samples(spp)
+    ref = one.accumulator()
+    two = rt.Scene.builtin(6, w, h)
+    two.set_pipelines(2)
+    two.render_samples(spp)
+    assert np.array_equal(ref, two.accumulator())
+    two.set_batch_paths(w * h)     # five batches of one sample, alternating pipelines
+    two.render_samples(spp)
+    one.render_samples(spp)
+    assert np.array_equal(one.accumulator(), two.accumulator())
+    info = two.info()
+    assert info["bvh_nodes"] + 1 == info["leaves_in_tree"] and info["device_bytes"] > 0
+
+
 def test_camera_entry_points_and_finalize():
     s = rt.Scene.builtin(6, 40, 40)
     o = ob.OracleScene.builtin(6, 40, 40)
