@@ -836,7 +836,10 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     sc->info.leaves_tested_first = n_global;
     sc->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     sc->d.n_global = n_global;
-    for (int i = 0; i < 7; ++i) sc->d.global_refs[i] = global_refs[i];
+    {
+        std::vector<uint32_t> g(global_refs, global_refs + 7);
+        if ((e = upload(sc, g, &sc->d.global_refs))) return bail(e);
+    }
     *out = sc;
     return RT_OK;
 }
@@ -910,11 +913,15 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
             hipStream_t st = n_pipes > 1 ? q.stream : c->stream;
             EventPair* ep;
             if ((e = phase_begin(c, st, 0, &ep))) return e;
-            launch_raygen(st, c->max_blocks, dcam, b, seed, q.ray_o[0], q.ray_d[0], q.thr[0], q.counts, n_counts);
+            // leaves kept out of the tree: tested by ray generation for the camera rays (by the counting pass when
+            // the work counters are on), by a pass of their own for the rays shade creates
+            const bool raygen_first_leaves = sc->d.n_global != 0 && counters == nullptr;
+            launch_raygen(st, c->max_blocks, sc->d, dcam, b, seed, q.ray_o[0], q.ray_d[0], q.thr[0], raygen_first_leaves ? q.hits : nullptr,
+                          q.counts, n_counts);
             if ((e = phase_end(st, ep))) return e;
             int cur = 0;
             for (uint32_t bounce = 0; bounce < cam->max_depth; ++bounce) {
-                if (sc->d.n_global != 0) {
+                if (sc->d.n_global != 0 && !(bounce == 0 && raygen_first_leaves)) {
                     if ((e = phase_begin(c, st, 4, &ep))) return e;
                     launch_first_leaves(st, c->max_blocks, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur], q.ray_d[cur], q.hits, counters);
                     if ((e = phase_end(st, ep))) return e;

@@ -118,13 +118,14 @@ struct Builder {
                 bx.mx[a] += eps;
             }
         }
+        // layout: see rt_device.h
         float* n = nodes + 16 * (size_t)node;
-        if (side == 0) {
-            n[0] = bx.mn[0]; n[1] = bx.mn[1]; n[2] = bx.mn[2]; n[3] = bx.mx[0]; n[4] = bx.mx[1]; n[5] = bx.mx[2];
-        } else {
-            n[6] = bx.mn[0]; n[7] = bx.mn[1]; n[8] = bx.mn[2]; n[9] = bx.mx[0]; n[10] = bx.mx[1]; n[11] = bx.mx[2];
-        }
+        float* xy = n + 4 * side;
+        xy[0] = bx.mn[0]; xy[1] = bx.mn[1]; xy[2] = bx.mx[0]; xy[3] = bx.mx[1];
+        n[8 + 2 * side] = bx.mn[2];
+        n[9 + 2 * side] = bx.mx[2];
         std::memcpy(&n[12 + side], &ref, 4);
+        n[14 + side] = widen ? 1.0000002f : 1.0f;
     }
 
     // Fills node `node` for range [b, e), e - b >= 2.  With `deferred` set, subranges of at
@@ -134,8 +135,6 @@ struct Builder {
         uint32_t d = max_depth.load(std::memory_order_relaxed);
         while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
         size_t mid = split(b, e, depth);
-        float* n = nodes + 16 * (size_t)node;
-        n[14] = 0.0f; n[15] = 0.0f;
         size_t rb[2] = {b, mid}, re[2] = {mid, e};
         for (int side = 0; side < 2; ++side) {
             size_t cnt = re[side] - rb[side];
@@ -153,6 +152,62 @@ struct Builder {
 };
 
 }  // namespace
+
+// Renumbers the nodes: breadth-first for the first BREADTH_FIRST_NODES (the top of the tree,
+// which every ray walks, becomes one contiguous block at the start of the array), then each
+// remaining subtree depth-first, parents before children.
+static void renumber(FlatBvh& bvh) {
+    constexpr uint32_t BREADTH_FIRST_NODES = 1024;
+    const uint32_t n = bvh.n_nodes;
+    if (n == 0) return;
+    auto child = [&](uint32_t node, int side) {
+        uint32_t r;
+        std::memcpy(&r, &bvh.nodes[16 * (size_t)node + 12 + side], 4);
+        return r;
+    };
+    std::vector<uint32_t> order;  // order[new] = old
+    order.reserve(n);
+    std::vector<uint32_t> frontier{bvh.root};
+    size_t head = 0;
+    while (head < frontier.size() && order.size() < BREADTH_FIRST_NODES) {
+        uint32_t node = frontier[head++];
+        order.push_back(node);
+        for (int side = 0; side < 2; ++side) {
+            uint32_t r = child(node, side);
+            if (!(r & 0x80000000u)) frontier.push_back(r);
+        }
+    }
+    std::vector<uint32_t> stack;
+    for (; head < frontier.size(); ++head) {
+        stack.push_back(frontier[head]);
+        while (!stack.empty()) {
+            uint32_t node = stack.back();
+            stack.pop_back();
+            order.push_back(node);
+            uint32_t l = child(node, 0), r = child(node, 1);
+            if (!(r & 0x80000000u)) stack.push_back(r);
+            if (!(l & 0x80000000u)) stack.push_back(l);
+        }
+    }
+    std::vector<uint32_t> new_of(n);
+    for (uint32_t i = 0; i < (uint32_t)order.size(); ++i) new_of[order[i]] = i;
+    std::vector<float> out(bvh.nodes.size());
+    for (uint32_t i = 0; i < (uint32_t)order.size(); ++i) {
+        const float* src = &bvh.nodes[16 * (size_t)order[i]];
+        float* dst = &out[16 * (size_t)i];
+        std::memcpy(dst, src, 64);
+        for (int side = 0; side < 2; ++side) {
+            uint32_t r;
+            std::memcpy(&r, &src[12 + side], 4);
+            if (!(r & 0x80000000u)) {
+                r = new_of[r];
+                std::memcpy(&dst[12 + side], &r, 4);
+            }
+        }
+    }
+    bvh.nodes.swap(out);
+    bvh.root = new_of[bvh.root];
+}
 
 FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads) {
     FlatBvh out;
@@ -191,6 +246,7 @@ FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads) {
     out.root = root;
     out.n_nodes = bld.next_node.load();
     out.max_depth = bld.max_depth.load();
+    renumber(out);
     return out;
 }
 

@@ -30,9 +30,14 @@ RT_HD bool ref_placed(uint32_t r) { return (r & REF_PLACED) != 0; }
 
 // ---------------------------------------------------------------------------
 // HBM layout (all arrays 16-byte aligned, one or more float4 per element):
-//   nodes   4 x float4 per BVH2 node (64 B):
-//             [0] = l.min.xyz, l.max.x   [1] = l.max.yz, r.min.xy
-//             [2] = r.min.z, r.max.xyz   [3] = bits(left ref), bits(right ref), 0, 0
+//   nodes   4 x float4 per BVH2 node (64 B), laid out for two-wide (packed) arithmetic:
+//             [0] = l.min.xy, l.max.xy   [1] = r.min.xy, r.max.xy
+//             [2] = l.min.z, l.max.z, r.min.z, r.max.z
+//             [3] = bits(left ref), bits(right ref), left slack, right slack
+//           slack multiplies the child's exit distance: 1 for a leaf whose box is the
+//           reference's own AABB (tested exactly), 1 + 2 ulp for conservative boxes.
+//           Nodes are numbered breadth-first for the first levels (the part of the tree every
+//           ray walks sits in a few KB at the start of the array), depth-first below.
 //   spheres 1 x float4: centre.xyz, radius                      (16 B)
 //   moving  2 x float4: centre0.xyz, radius | dcentre.xyz, 0     (32 B)
 //   quads   4 x float4: N.xyz, D | q.xyz, bits(material) |
@@ -108,7 +113,7 @@ struct DScene {
     uint32_t n_media;
     uint32_t n_materials;
     uint32_t n_global;         // leaves kept out of the tree: tested first for every ray
-    uint32_t global_refs[7];
+    const uint32_t* global_refs;  // n_global leaf references tested ahead of the tree
 };
 
 // Shading classes: rays of one class run the same code, so the shade kernel groups the rays of

@@ -16,8 +16,11 @@ struct BatchInfo {
 
 // max_blocks caps the grid (grid-stride kernels); upper_bound is a host-side
 // bound on the queue length, the exact length is read from counts[bounce].
-void launch_raygen(hipStream_t st, uint32_t max_blocks, const DCamera& cam, const BatchInfo& b, uint64_t seed, float4* ray_o, float4* ray_d,
-                   float4* thr, uint32_t* counts, uint32_t n_counts);
+// first_hits (may be NULL): where ray generation leaves, for every ray, its closest hit among the leaves
+// kept out of the tree (scenes with sc.n_global != 0); the extend kernel starts from that record.  With
+// NULL the caller runs launch_first_leaves before the first launch_extend, as it does before all later ones.
+void launch_raygen(hipStream_t st, uint32_t max_blocks, const DScene& sc, const DCamera& cam, const BatchInfo& b, uint64_t seed, float4* ray_o,
+                   float4* ray_d, float4* thr, uint2* first_hits, uint32_t* counts, uint32_t n_counts);
 void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam, uint64_t seed, uint32_t sample, const uint32_t* pixels,
                          unsigned long long n, rt_ray* out);
 // Lane-count thresholds of the extend kernel's loop (see k_extend).
@@ -28,7 +31,7 @@ struct ExtendTuning {
 };
 int extend_blocks_per_cu(bool counting);
 size_t extend_overflow_bytes(uint32_t blocks);
-// Must run before launch_extend when sc.n_global != 0 (the extend kernel then starts every ray from hits[]).
+// The same computation as a pass of its own over a queue.
 void launch_first_leaves(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
                          uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits, DCounters* counters);
 // resident_blocks: CUs x extend_blocks_per_cu(counters != nullptr); stack_overflow: extend_overflow_bytes(resident_blocks) bytes

@@ -142,9 +142,6 @@ RT_D bool boundary_root(const DScene& sc, const DMedium& m, float3 o, float3 d, 
     return any;
 }
 
-// leaf in world space that is not a medium: top four bits 1kk0 with kk != 11
-RT_D bool exact_leaf_box(uint32_t ref) { return ((ref >> 28) & 9u) == 8u && (ref >> 29) != 7u; }
-
 // What a medium needs to start its random stream: (seed, pixel, sample) of the path and the
 // bounce.  The render path only carries the path's index in the batch and derives the rest
 // when a medium is actually entered.
@@ -237,33 +234,29 @@ struct PrivateStack {  // per-lane array (scratch memory): used by the record-ba
 };
 
 // Stack of the render path's extend kernel.  An entry is 64 bits: (entry distance << 32) | ref.
-// The first LDS_STACK levels live in LDS, laid out [level][lane] so that the 64 lanes of a
+// The first LEVELS levels live in LDS, laid out [level][lane] so that the 64 lanes of a
 // wave always hit different banks whatever their stack depths; deeper levels (10 M-leaf trees)
 // go to a per-wave area in global memory with the same layout.  The two address spaces are
 // spelled out so that every access compiles to a plain ds_ or global_ instruction.
-#ifndef RT_LDS_STACK
-#define RT_LDS_STACK 12
-#endif
-static constexpr int LDS_STACK = RT_LDS_STACK;
-static constexpr int OVERFLOW_STACK = STACK_SIZE - LDS_STACK;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(1))) unsigned long long global_u64;
+template <int LEVELS>
 struct WaveStack {
     lds_u64* lds;     // this lane's column: level k at lds[64 * k]
-    global_u64* ovf;  // level LDS_STACK + k at ovf[64 * k]
+    global_u64* ovf;  // level LEVELS + k at ovf[64 * k]
     int sp = 0;
     RT_D void push(uint32_t r, float tt) {
         unsigned long long e = ((unsigned long long)__float_as_uint(tt) << 32) | r;
-        if (sp < LDS_STACK) lds[64 * sp] = e;
-        else ovf[64 * (sp - LDS_STACK)] = e;
+        if (sp < LEVELS) lds[64 * sp] = e;
+        else ovf[64 * (sp - LEVELS)] = e;
         ++sp;
     }
     RT_D bool pop(uint32_t& r, float& tt) {
         if (sp == 0) return false;
         --sp;
         unsigned long long e;
-        if (sp < LDS_STACK) e = lds[64 * sp];
-        else e = ovf[64 * (sp - LDS_STACK)];
+        if (sp < LEVELS) e = lds[64 * sp];
+        else e = ovf[64 * (sp - LEVELS)];
         r = (uint32_t)e;
         tt = __uint_as_float((uint32_t)(e >> 32));
         return true;
@@ -294,35 +287,53 @@ RT_D uint32_t pop_next(Stack& st, float tmax) {
     return REF_DONE;
 }
 
+// Where inner nodes are read from: the array in global memory, or for the first n_top nodes
+// (the top levels of the tree, numbered breadth-first) a copy in LDS.
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float4v lds_float4v;
+RT_D float4 f4(float4v v) { return make_float4(v.x, v.y, v.z, v.w); }
+struct NodeSource {
+    const float4* nodes;
+    const float4* top;   // LDS copy of nodes[0 .. n_top) (generic pointer to shared memory), or unused
+    uint32_t n_top;
+};
+typedef float float2v __attribute__((ext_vector_type(2)));
+
 // One inner node: slab-tests both children, continues with the nearer one and stacks the
 // other.  Returns the next reference (inner node, leaf, or REF_DONE).
-template <bool COUNT, class Stack>
-RT_D uint32_t node_step(const DScene& sc, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr) {
+//
+// The slab distances are (bound - origin) * (1 / direction), each rounded once, exactly the
+// arithmetic of AABBx2::hit (src/math/aabb.rs:127-167); they are evaluated two at a time with
+// packed subtract / multiply, which round like the scalar instructions.  A conservative box
+// (inner node, placed leaf, medium) has its exit distance widened by the node's slack factor;
+// the box of a leaf that sits in world space is the reference's own AABB and is tested with
+// slack 1, so the same leaves get tested as in the reference.
+template <bool COUNT, bool LDS_TOP, class Stack>
+RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr) {
     if (COUNT) pr.nodes++;
-    const float4* n = sc.nodes + 4 * (size_t)cur;
-    float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+    float4 n0, n1, n2, n3;
+    if (LDS_TOP && cur < src.n_top) {
+        const lds_float4v* n = (const lds_float4v*)src.top + 4 * cur;
+        n0 = f4(n[0]); n1 = f4(n[1]); n2 = f4(n[2]); n3 = f4(n[3]);
+    } else {
+        const float4* n = src.nodes + 4 * (size_t)cur;
+        n0 = n[0]; n1 = n[1]; n2 = n[2]; n3 = n[3];
+    }
     float l_in, r_in, l_out, r_out;
     {
-#pragma clang fp contract(fast)
+        const float2v oxy = {r.o.x, r.o.y}, ixy = {r.inv.x, r.inv.y}, ozz = {r.o.z, r.o.z}, izz = {r.inv.z, r.inv.z};
         // NaNs (0 * inf) drop out of fminf/fmaxf, as they do out of simd_min/simd_max in the reference
-        float lx0 = (n0.x - r.o.x) * r.inv.x, lx1 = (n0.w - r.o.x) * r.inv.x;
-        float ly0 = (n0.y - r.o.y) * r.inv.y, ly1 = (n1.x - r.o.y) * r.inv.y;
-        float lz0 = (n0.z - r.o.z) * r.inv.z, lz1 = (n1.y - r.o.z) * r.inv.z;
-        float rx0 = (n1.z - r.o.x) * r.inv.x, rx1 = (n2.y - r.o.x) * r.inv.x;
-        float ry0 = (n1.w - r.o.y) * r.inv.y, ry1 = (n2.z - r.o.y) * r.inv.y;
-        float rz0 = (n2.x - r.o.z) * r.inv.z, rz1 = (n2.w - r.o.z) * r.inv.z;
-        l_in = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), r.tmin));
-        l_out = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), tmax));
-        r_in = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), r.tmin));
-        r_out = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), tmax));
+        const float2v l0 = (float2v{n0.x, n0.y} - oxy) * ixy, l1 = (float2v{n0.z, n0.w} - oxy) * ixy;
+        const float2v r0 = (float2v{n1.x, n1.y} - oxy) * ixy, r1 = (float2v{n1.z, n1.w} - oxy) * ixy;
+        const float2v lz = (float2v{n2.x, n2.y} - ozz) * izz, rz = (float2v{n2.z, n2.w} - ozz) * izz;
+        l_in = fmaxf(fmaxf(fminf(l0.x, l1.x), fminf(l0.y, l1.y)), fmaxf(fminf(lz.x, lz.y), r.tmin));
+        l_out = fminf(fminf(fmaxf(l0.x, l1.x), fmaxf(l0.y, l1.y)), fminf(fmaxf(lz.x, lz.y), tmax));
+        r_in = fmaxf(fmaxf(fminf(r0.x, r1.x), fminf(r0.y, r1.y)), fmaxf(fminf(rz.x, rz.y), r.tmin));
+        r_out = fminf(fminf(fmaxf(r0.x, r1.x), fmaxf(r0.y, r1.y)), fminf(fmaxf(rz.x, rz.y), tmax));
     }
-    uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
-    // Inner boxes (and the world-space bounds of placed leaves and media) are conservative:
-    // their exit distance is widened by 2 ulp.  The box of a leaf that sits in world space
-    // is the reference's own AABB and is tested exactly as AABBx2::hit does
-    // (src/math/aabb.rs:127-167), so the same leaves get tested as in the reference.
-    bool hl = l_in <= l_out * (exact_leaf_box(left) ? 1.0f : 1.0000002f);
-    bool hr = r_in <= r_out * (exact_leaf_box(right) ? 1.0f : 1.0000002f);
+    const uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+    const bool hl = l_in <= l_out * n3.z;
+    const bool hr = r_in <= r_out * n3.w;
     if (hl && hr) {
         bool left_first = l_in <= r_in;
         st.push(left_first ? right : left, left_first ? r_in : l_in);
@@ -375,6 +386,20 @@ RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_
     }
 }
 
+// Starting point of a ray's traversal when the scene keeps leaves out of the tree: the closest
+// hit among those leaves, as the hit record the extend kernel then improves on.  Ray generation
+// computes it with the ray still in registers; for the rays shade creates, a streaming pass of
+// its own (k_first_leaves) is faster than doing it inside the shade kernel's tile loop.
+RT_D uint2 first_leaves_hit(const DScene& sc, const BatchInfo& b, uint64_t seed, uint32_t bounce, float4 ro, float4 rd) {
+    BatchMediumKey key{seed, __float_as_uint(rd.w), bounce, b};
+    TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
+    float tmax = RT_INF;
+    uint32_t best = REF_NONE;
+    Probe pr;
+    global_leaves<false>(sc, r, tmax, best, key, pr);
+    return make_uint2(__float_as_uint(tmax), best);
+}
+
 // ---------------------------------------------------------------------------
 // Closest hit over the flattened BVH (one ray per call): returns the leaf
 // reference (REF_NONE on a miss) and its t.
@@ -386,9 +411,10 @@ RT_D uint32_t closest_hit(const DScene& sc, float3 o, float3 d, float time, floa
     TravRay r = make_trav_ray(o, d, time, tmin);
     global_leaves<COUNT>(sc, r, tmax, best, key, pr);
     PrivateStack st;
+    const NodeSource src{sc.nodes, nullptr, 0};
     uint32_t cur = sc.root == REF_NONE ? REF_DONE : sc.root;
     while (cur != REF_DONE) {
-        if (!ref_is_leaf(cur)) cur = node_step<COUNT>(sc, r, cur, tmax, st, pr);
+        if (!ref_is_leaf(cur)) cur = node_step<COUNT, false>(src, r, cur, tmax, st, pr);
         else cur = leaf_step<COUNT>(sc, r, cur, tmax, best, key, st, pr);
     }
     t_hit = tmax;
@@ -750,9 +776,9 @@ RT_D void primary_ray(const DCamera& cam, uint64_t seed, uint32_t pixel, uint32_
 
 // One thread per path of the batch.  Path index = s_local * n_pixels + pixel_local,
 // which is also the initial queue slot.
-__global__ __launch_bounds__(256) void k_raygen(DCamera cam, BatchInfo b, uint64_t seed, float4* __restrict__ ray_o,
-                                                float4* __restrict__ ray_d, float4* __restrict__ thr, uint32_t* __restrict__ counts,
-                                                uint32_t n_counts) {
+__global__ __launch_bounds__(256) void k_raygen(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, float4* __restrict__ ray_o,
+                                                float4* __restrict__ ray_d, float4* __restrict__ thr, uint2* __restrict__ first_hits,
+                                                uint32_t* __restrict__ counts, uint32_t n_counts) {
     const uint32_t total = b.n_pixels * b.n_samples;
     if (blockIdx.x == 0) {
         for (uint32_t i = threadIdx.x; i < n_counts; i += blockDim.x) counts[i] = (i == 0) ? total : 0u;
@@ -763,9 +789,11 @@ __global__ __launch_bounds__(256) void k_raygen(DCamera cam, BatchInfo b, uint64
         float3 origin, dir;
         float time;
         primary_ray(cam, seed, pixel, b.first_sample + s_local, origin, dir, time);
-        ray_o[i] = make_float4(origin.x, origin.y, origin.z, time);
-        ray_d[i] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(i));
+        const float4 ro = make_float4(origin.x, origin.y, origin.z, time), rd = make_float4(dir.x, dir.y, dir.z, __uint_as_float(i));
+        ray_o[i] = ro;
+        ray_d[i] = rd;
         thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        if (first_hits) first_hits[i] = first_leaves_hit(sc, b, seed, 0, ro, rd);
     }
 }
 
@@ -800,16 +828,35 @@ __global__ __launch_bounds__(256) void k_primary_rays(DCamera cam, uint64_t seed
 #endif
 static constexpr int EXTEND_BLOCK = 256;
 
+// LDS of one block: 24 KiB, spent either on 12 stack levels per lane, or - for a tree small
+// enough to be copied into LDS whole - on 8 stack levels and the tree (a copy of only the top
+// levels of a larger tree does not pay: those nodes are served by the L1 cache anyway, and
+// more LDS per block means fewer resident waves).
+static constexpr int SMALL_TREE_NODES = 128;
+template <bool SMALL_TREE> struct ExtendLds {
+    static constexpr int STACK_LEVELS = SMALL_TREE ? 8 : 12;
+    static constexpr int TOP_NODES = SMALL_TREE ? SMALL_TREE_NODES : 0;
+};
+static constexpr int MIN_LDS_STACK = 8;
+static constexpr int OVERFLOW_STACK = STACK_SIZE - MIN_LDS_STACK;
 #ifndef RT_EXTEND_WAVES
 #define RT_EXTEND_WAVES 6  // resident waves per SIMD the register allocation aims for
 #endif
-template <bool COUNT>
+template <bool COUNT, bool SMALL_TREE>
 __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_EXTEND_WAVES, RT_EXTEND_WAVES))) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                          const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
                                                          const float4* __restrict__ ray_d, uint2* __restrict__ hits,
                                                          unsigned long long* __restrict__ stack_overflow, ExtendTuning tune,
                                                          DCounters* counters) {
+    constexpr int LDS_STACK = ExtendLds<SMALL_TREE>::STACK_LEVELS, LDS_TOP_NODES = ExtendLds<SMALL_TREE>::TOP_NODES;
     __shared__ unsigned long long s_stack[EXTEND_BLOCK / 64][LDS_STACK][64];
+    __shared__ float4 s_top[LDS_TOP_NODES > 0 ? 4 * LDS_TOP_NODES : 1];
+    NodeSource src{sc.nodes, s_top, 0};
+    if (LDS_TOP_NODES > 0) {  // the block's copy of the tree
+        src.n_top = min(sc.n_nodes, (uint32_t)LDS_TOP_NODES);
+        for (uint32_t i = threadIdx.x; i < 4 * src.n_top; i += EXTEND_BLOCK) s_top[i] = sc.nodes[i];
+        __syncthreads();
+    }
     const uint32_t n = counts[bounce];
     const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
     const uint32_t wave = blockIdx.x * (EXTEND_BLOCK / 64) + wave_in_block, n_waves = gridDim.x * (EXTEND_BLOCK / 64);
@@ -821,7 +868,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(RT
     uint32_t next = blk * 64u;
     uint32_t blk_end = min(n, next + 64u);
 
-    WaveStack st;
+    WaveStack<LDS_STACK> st;
     st.lds = (lds_u64*)&s_stack[wave_in_block][0][lane];
     st.ovf = (global_u64*)(stack_overflow + ((size_t)wave * OVERFLOW_STACK) * 64 + lane);
     Probe pr;
@@ -901,7 +948,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(RT
 #if RT_LANE_STATS == 1
             if (COUNT) slots++;
 #endif
-            if (at_inner) cur = node_step<COUNT>(sc, r, cur, tmax, st, pr);
+            if (at_inner) cur = node_step<COUNT, SMALL_TREE>(src, r, cur, tmax, st, pr);
         }
         // sphere and quad leaves
         {
@@ -1325,10 +1372,11 @@ static inline uint32_t grid_for(unsigned long long n, uint32_t max_blocks) {
     return (uint32_t)blocks;
 }
 
-void launch_raygen(hipStream_t st, uint32_t max_blocks, const DCamera& cam, const BatchInfo& b, uint64_t seed, float4* ray_o, float4* ray_d,
-                   float4* thr, uint32_t* counts, uint32_t n_counts) {
+void launch_raygen(hipStream_t st, uint32_t max_blocks, const DScene& sc, const DCamera& cam, const BatchInfo& b, uint64_t seed, float4* ray_o,
+                   float4* ray_d, float4* thr, uint2* first_hits, uint32_t* counts, uint32_t n_counts) {
     uint32_t total = b.n_pixels * b.n_samples;
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for(total, max_blocks)), dim3(256), 0, st, cam, b, seed, ray_o, ray_d, thr, counts, n_counts);
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(total, max_blocks)), dim3(256), 0, st, sc, cam, b, seed, ray_o, ray_d, thr,
+                       sc.n_global != 0 ? first_hits : nullptr, counts, n_counts);
 }
 
 void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam, uint64_t seed, uint32_t sample, const uint32_t* pixels,
@@ -1342,12 +1390,17 @@ void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam
 // share of the queue on an almost empty chip.
 int extend_blocks_per_cu(bool counting) {
     int a = 0;
-    hipError_t e = counting ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_extend<true>, EXTEND_BLOCK, 0)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_extend<false>, EXTEND_BLOCK, 0);
+    int b = 0;
+    hipError_t e = counting ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_extend<true, false>, EXTEND_BLOCK, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_extend<false, false>, EXTEND_BLOCK, 0);
     if (e != hipSuccess) a = 0;
+    e = counting ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_extend<true, true>, EXTEND_BLOCK, 0)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_extend<false, true>, EXTEND_BLOCK, 0);
+    if (e != hipSuccess) b = 0;
+    a = std::min(a, b);
     (void)hipGetLastError();
     // a block whose LDS divides the CU's 160 KiB exactly does not get the last slot in practice
-    int by_lds = (int)((160u * 1024u - 1024u) / sizeof(unsigned long long[EXTEND_BLOCK / 64][LDS_STACK][64]));
+    int by_lds = (int)((160u * 1024u - 1024u) / (24u * 1024u + 16u));  // both variants: 24 KiB per block
     return std::min(a, by_lds);
 }
 // bytes of the extend kernel's stack overflow area for a grid of `blocks` blocks
@@ -1364,10 +1417,9 @@ void launch_extend(hipStream_t st, uint32_t resident_blocks, uint32_t upper_boun
                    uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits,
                    unsigned long long* stack_overflow, const ExtendTuning& tune, DCounters* counters) {
     dim3 grid(grid_for(upper_bound, resident_blocks));
-    if (counters)
-        hipLaunchKernelGGL(k_extend<true>, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, stack_overflow, tune, counters);
-    else
-        hipLaunchKernelGGL(k_extend<false>, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, stack_overflow, tune, counters);
+    const bool small_tree = sc.n_nodes <= (uint32_t)SMALL_TREE_NODES;
+    auto kernel = counters ? (small_tree ? k_extend<true, true> : k_extend<true, false>) : (small_tree ? k_extend<false, true> : k_extend<false, false>);
+    hipLaunchKernelGGL(kernel, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, stack_overflow, tune, counters);
 }
 
 void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const DCamera& cam, const BatchInfo& b,
@@ -1377,11 +1429,8 @@ void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, con
     unsigned long long tiles = ((unsigned long long)upper_bound + SHADE_TILE - 1) / SHADE_TILE;
     uint32_t grid = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(tiles, 1), max_blocks);
     static const bool unsorted = getenv("RT_AMD_SHADE_UNSORTED") != nullptr;  // A/B experiment
-    if (unsorted)
-        hipLaunchKernelGGL(k_shade_unsorted, dim3(grid), dim3(SHADE_BLOCK), 0, st, sc, cam, b, seed, bounce, counts, tex_count, tex_list, ray_o,
-                           ray_d, thr, hits, out_o, out_d, out_thr, radiance);
-    else
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, st, sc, cam, b, seed, bounce, counts, tex_count, tex_list, ray_o, ray_d, thr,
+    auto kernel = unsorted ? k_shade_unsorted : k_shade;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(SHADE_BLOCK), 0, st, sc, cam, b, seed, bounce, counts, tex_count, tex_list, ray_o, ray_d, thr,
                        hits, out_o, out_d, out_thr, radiance);
     if (scene_has_textures)
         hipLaunchKernelGGL(k_shade_textured, dim3(grid_for(upper_bound, max_blocks)), dim3(256), 0, st, sc, cam, b, seed, bounce, counts,
