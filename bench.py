@@ -145,6 +145,17 @@ def main():
         scene.set_counters(False)
         del scratch
         per_segment = {k: round(cnt[k] / max(1, cnt["segments"]), 3) for k in ("node_visits", "sphere_tests", "quad_tests", "medium_tests", "hits")}
+        # the same step once more with one pipeline, so that no other kernel shares the chip with k_extend
+        scene.set_pipelines(1)
+        scene.set_phase_timing(True)
+        iso = torch.zeros_like(acc)
+        scene.render_accumulate_device(iso.data_ptr(), nxt - spp, spp, seed=args.seed)
+        torch.cuda.synchronize()
+        scene.synchronize()
+        iso_ms, iso_launches = scene.phase_ms()["extend"]
+        scene.set_phase_timing(False)
+        scene.set_pipelines(2)
+        del iso
         ext_ms, ext_launches = phases["extend"]
         # segments of the whole timed region: the counted step times the number of steps (steps differ
         # only in their sample numbers; their segment counts agree to ~0.1 %)
@@ -167,6 +178,9 @@ def main():
                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "bytes_per_launch": round(ext_bytes / max(1, ext_launches), 1), "launches": ext_launches,
                     "avg_launch_ms": round(ext_ms / max(1, ext_launches), 5), "segments_per_sample": round(segments / cnt["samples"], 4),
+                    "alone": {"note": "one step with a single pipeline: k_extend does not share the chip with the other batch's kernels",
+                              "avg_launch_ms": round(iso_ms / max(1, iso_launches), 5),
+                              "achieved": round(EXTEND_BYTES_PER_SEGMENT * cnt["segments"] / (iso_ms * 1e-3) / 1e9, 2) if iso_ms > 0 else 0.0},
                     "valu": {"achieved": round(achieved_tf, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved_tf / FP32_VECTOR_PEAK_TFLOPS, 5)},
                     "work_per_segment": per_segment, "phase_ms": {k: round(v[0], 3) for k, v in phases.items()}}
