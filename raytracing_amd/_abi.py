@@ -149,6 +149,11 @@ RTH_API = {
     "rth_hdr_render": (C.c_int, [_P, _P]),
     "rth_realtime_render": (C.c_int, [_P, _P]),
     "rth_download_accumulator": (C.c_int, [_P, _P]),
+    "rth_render_to_image": (C.c_int, [_P, _U64, C.c_char_p, _P]),
+    "rth_save_checkpoint": (C.c_int, [_P, C.c_char_p]),
+    "rth_load_checkpoint": (C.c_int, [_P, C.c_char_p]),
+    "rth_write_exr": (C.c_int, [C.c_char_p, _U32, _U32, _P]),
+    "rth_write_pfm": (C.c_int, [C.c_char_p, _U32, _U32, _P]),
     "rth_change_pitch_yaw_by": (C.c_int, [_P, _F, _F]),
     "rth_move_by": (C.c_int, [_P, _FP]),
     "rth_set_exposure": (C.c_int, [_P, _F]),

@@ -182,6 +182,17 @@ int rth_download_accumulator(void* p, float* out) {
         std::memcpy(out, acc.data(), acc.size() * sizeof(float));
     });
 }
+// out_rgba may be NULL; path may be NULL or empty (no file)
+int rth_render_to_image(void* p, uint64_t sample_count, const char* path, float* out_rgba) {
+    return guard([&] {
+        std::vector<float> img = cam(p)->render_to_image((size_t)sample_count, path ? path : "");
+        if (out_rgba) std::memcpy(out_rgba, img.data(), img.size() * sizeof(float));
+    });
+}
+int rth_save_checkpoint(void* p, const char* path) { return guard([&] { cam(p)->save_checkpoint(path); }); }
+int rth_load_checkpoint(void* p, const char* path) { return guard([&] { cam(p)->load_checkpoint(path); }); }
+int rth_write_exr(const char* path, uint32_t w, uint32_t h, const float* rgba) { return guard([&] { write_exr(path, w, h, rgba); }); }
+int rth_write_pfm(const char* path, uint32_t w, uint32_t h, const float* rgba) { return guard([&] { write_pfm(path, w, h, rgba); }); }
 int rth_change_pitch_yaw_by(void* p, float dp, float dy) { return guard([&] { cam(p)->change_pitch_yaw_by(dp, dy); }); }
 int rth_move_by(void* p, const float* step) { return guard([&] { cam(p)->move_by(v3(step)); }); }
 int rth_set_exposure(void* p, float e) { return guard([&] { cam(p)->set_exposure(e); }); }

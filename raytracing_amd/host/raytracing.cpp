@@ -484,6 +484,14 @@ std::vector<float> Camera::download_accumulator() {
     return acc;
 }
 
+void Camera::upload_accumulator(const float* acc, size_t samples) {
+    ensure_backend();
+    force_update_raytracing_camera();
+    size_t n = render_resolution_.first * render_resolution_.second;
+    check(rt_buffer_upload(ctx_, d_acc_, acc, n * 4 * sizeof(float)), "rt_buffer_upload");
+    samples_ = samples;
+}
+
 void Camera::change_pitch_yaw_by(float delta_pitch, float delta_yaw) {  // :149-160
     if (delta_pitch == 0.0f && delta_yaw == 0.0f) return;
     pitch_ += delta_pitch;

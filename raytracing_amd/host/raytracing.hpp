@@ -205,6 +205,10 @@ class RenderError : public std::runtime_error {
 rt_camera_desc raytracing_camera(size_t width, size_t height, size_t max_depth, float vfov, Vec3 look_from, Vec3 look_at, Vec3 vup,
                                  float defocus_angle, float focus_dist, Colour background_colour);
 
+// The image file of `--image` (src/main.rs:171-183): RGBA f32, rows top to bottom.
+void write_exr(const std::string& path, size_t width, size_t height, const float* rgba);
+void write_pfm(const std::string& path, size_t width, size_t height, const float* rgba);
+
 // ---- src/camera.rs:10-202 --------------------------------------------------------
 class Camera {
   public:
@@ -222,6 +226,13 @@ class Camera {
     std::vector<Vec3> hdr_render();               // one more sample, sqrt(mean)
     // Not in the reference: `n` consecutive empty_render calls in one GPU submission.
     void render_samples(uint32_t n);
+    // `--image` (src/main.rs:157-186): sample_count - 1 empty_render calls and one hdr_render; returns the
+    // W*H RGBA floats (alpha 1) and, unless `path` is empty, writes them as OpenEXR (or PFM for "*.pfm").
+    std::vector<float> render_to_image(size_t sample_count, const std::string& path);
+    // Not in the reference: the accumulation buffer, sample count and seed to a file and back, so that a
+    // long render can be continued by another process (the sample numbers carry on where they stopped).
+    void save_checkpoint(const std::string& path);
+    void load_checkpoint(const std::string& path);
     void change_pitch_yaw_by(float delta_pitch, float delta_yaw);
     void move_by(Vec3 step);
     Vec3 forward() const { return direction_; }
@@ -245,6 +256,7 @@ class Camera {
     const FlatScene& flat_scene() const { return flat_; }
     float* device_accumulator() { ensure_backend(); return d_acc_; }
     std::vector<float> download_accumulator();        // W*H*4 floats
+    void upload_accumulator(const float* acc, size_t samples);  // replaces the buffer: `samples` samples per pixel are in it
 
   private:
     void ensure_backend();

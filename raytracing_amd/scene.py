@@ -21,6 +21,21 @@ def _f3(v):
     return (C.c_float * 3)(*[float(x) for x in v])
 
 
+def write_exr(path, rgba):
+    """RGBA float32 image (H, W, 4) as an uncompressed scanline OpenEXR file."""
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    host = _abi.lib_host()
+    if host.rth_write_exr(path.encode(), rgba.shape[1], rgba.shape[0], rgba.ctypes.data):
+        raise RenderError(host.rth_last_error().decode())
+
+
+def write_pfm(path, rgba):
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    host = _abi.lib_host()
+    if host.rth_write_pfm(path.encode(), rgba.shape[1], rgba.shape[0], rgba.ctypes.data):
+        raise RenderError(host.rth_last_error().decode())
+
+
 def load_earth():
     """The decoded earthmap.jpg (PIL 12.2 / libjpeg-turbo) as H x W x 3 uint8."""
     w, h = _abi.EARTH_SIZE
@@ -184,6 +199,20 @@ class Scene(BuilderCalls):
         out = np.empty((h, w, 4), np.float32)
         self._check_host(self.host.rth_download_accumulator(self._h, out.ctypes.data))
         return out
+
+    def render_to_image(self, sample_count, path=None):
+        """`--image` of the reference: sample_count - 1 samples, then hdr_render; RGBA float32 (alpha 1),
+        written to `path` as OpenEXR (or PFM for *.pfm) when given."""
+        w, h = self.resolution
+        out = np.empty((h, w, 4), np.float32)
+        self._check_host(self.host.rth_render_to_image(self._h, sample_count, path.encode() if path else None, out.ctypes.data))
+        return out
+
+    def save_checkpoint(self, path):
+        self._check_host(self.host.rth_save_checkpoint(self._h, path.encode()))
+
+    def load_checkpoint(self, path):
+        self._check_host(self.host.rth_load_checkpoint(self._h, path.encode()))
 
     def change_pitch_yaw_by(self, dp, dy):
         self._check_host(self.host.rth_change_pitch_yaw_by(self._h, dp, dy))
