@@ -32,7 +32,8 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X FP32 vector, spec
 # the extend kernel reads one ray record (origin, direction, time, throughput, pixel, sample:
 # 48 B) and writes one hit record (t, primitive, u, v: 16 B).
 EXTEND_BYTES_PER_SEGMENT = 64
-FLOPS = {"node_visits": 50, "sphere_tests": 30, "quad_tests": 45, "hits": 20}
+# a node visit slab-tests the four child boxes of a node: 4 x 25 flops (the count for two-child nodes was 2 x 25)
+FLOPS = {"node_visits": 100, "sphere_tests": 30, "quad_tests": 45, "hits": 20}
 
 
 def parse_args():

@@ -745,10 +745,12 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         };
         bool ok = bvh.root == REF_NONE || ref_ok(bvh.root);
         for (uint32_t i = 0; ok && i < bvh.n_nodes; ++i) {
-            uint32_t l, r;
-            std::memcpy(&l, &bvh.nodes[16 * (size_t)i + 12], 4);
-            std::memcpy(&r, &bvh.nodes[16 * (size_t)i + 13], 4);
-            ok = ref_ok(l) && ref_ok(r);
+            for (int k = 0; ok && k < rt::BVH_WIDTH; ++k) {
+                uint32_t r;
+                std::memcpy(&r, &bvh.nodes[rt::NODE_FLOATS * (size_t)i + rt::NODE_REFS_AT + k], 4);
+                const bool empty_slot = bvh.nodes[rt::NODE_FLOATS * (size_t)i + rt::NODE_SLACK_AT + k] == 0.0f;
+                ok = empty_slot || ref_ok(r);
+            }
         }
         for (uint32_t i = 0; ok && i < n_global; ++i) ok = ref_ok(global_refs[i]);
         if (!ok) return fail(RT_ERR_HIP, "internal error: the flattened BVH holds an invalid reference");

@@ -5,6 +5,7 @@
 #include "rt_bvh.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cfloat>
 #include <cmath>
@@ -153,6 +154,93 @@ struct Builder {
 
 }  // namespace
 
+// Folds the binary tree into one with four children per node: a node takes over the children of
+// inner children, largest box first, until its four slots are full.  Boxes, references and slack factors are copied
+// unchanged, so what is tested for a leaf does not depend on the width.
+// Wide node (32 floats): child k's min.x min.y max.x max.y at 4k; z ranges (min, max) at 16 + 2k;
+// references at 24 + k; slack at 28 + k (0 marks an empty slot: such a child is never entered).
+static void fold_to_four(FlatBvh& bvh) {
+    const uint32_t n2 = bvh.n_nodes;
+    if (n2 == 0) return;
+    const std::vector<float> in = std::move(bvh.nodes);
+    struct Child { float xy[4], z[2], slack; uint32_t ref; };
+    auto child_of = [&](uint32_t node, int side) {
+        const float* n = &in[16 * (size_t)node];
+        Child c;
+        std::memcpy(c.xy, n + 4 * side, 16);
+        c.z[0] = n[8 + 2 * side];
+        c.z[1] = n[9 + 2 * side];
+        std::memcpy(&c.ref, n + 12 + side, 4);
+        c.slack = n[14 + side];
+        return c;
+    };
+    std::vector<float> out;
+    out.reserve(in.size());
+    std::vector<uint32_t> new_of(n2, 0xFFFFFFFFu);
+    // pass 1: which binary nodes survive (the root, and every inner node that ends up as a child slot), in visiting order
+    std::vector<uint32_t> order{bvh.root};
+    new_of[bvh.root] = 0;
+    std::vector<std::array<Child, 4>> wide;
+    std::vector<int> wide_n;
+    uint32_t depth_max = 0;
+    std::vector<uint32_t> depth{1};
+    for (size_t head = 0; head < order.size(); ++head) {
+        const uint32_t node = order[head];
+        // start from the node's two children; while a slot is free, replace the inner child with the largest
+        // box surface by its own two children
+        std::array<Child, 4> slots{};
+        int k = 0;
+        slots[k++] = child_of(node, 0);
+        slots[k++] = child_of(node, 1);
+        auto area = [](const Child& c) {
+            float dx = c.xy[2] - c.xy[0], dy = c.xy[3] - c.xy[1], dz = c.z[1] - c.z[0];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        while (k < 4) {
+            int pick = -1;
+            for (int i = 0; i < k; ++i)
+                if (!(slots[i].ref & 0x80000000u) && (pick < 0 || area(slots[i]) > area(slots[pick]))) pick = i;
+            if (pick < 0) break;
+            const uint32_t inner = slots[pick].ref;
+            slots[pick] = child_of(inner, 0);
+            slots[k++] = child_of(inner, 1);
+        }
+        for (int i = 0; i < k; ++i) {
+            if (!(slots[i].ref & 0x80000000u)) {
+                new_of[slots[i].ref] = (uint32_t)order.size();
+                order.push_back(slots[i].ref);
+                depth.push_back(depth[head] + 1);
+            }
+        }
+        depth_max = std::max(depth_max, depth[head]);
+        wide.push_back(slots);
+        wide_n.push_back(k);
+    }
+    out.assign(32 * wide.size(), 0.0f);
+    for (size_t i = 0; i < wide.size(); ++i) {
+        float* n = &out[32 * i];
+        for (int k = 0; k < 4; ++k) {
+            Child c = wide[i][k];
+            if (k >= wide_n[i]) {  // empty slot
+                c = Child{};
+                c.ref = 0xFFFFFFFFu;
+                c.slack = 0.0f;
+            } else if (!(c.ref & 0x80000000u)) {
+                c.ref = new_of[c.ref];
+            }
+            std::memcpy(n + 4 * k, c.xy, 16);
+            n[16 + 2 * k] = c.z[0];
+            n[17 + 2 * k] = c.z[1];
+            std::memcpy(n + 24 + k, &c.ref, 4);
+            n[28 + k] = c.slack;
+        }
+    }
+    bvh.nodes.swap(out);
+    bvh.n_nodes = (uint32_t)wide.size();
+    bvh.root = 0;
+    bvh.max_depth = depth_max;
+}
+
 // Renumbers the nodes: breadth-first for the first BREADTH_FIRST_NODES (the top of the tree,
 // which every ray walks, becomes one contiguous block at the start of the array), then each
 // remaining subtree depth-first, parents before children.
@@ -160,9 +248,9 @@ static void renumber(FlatBvh& bvh) {
     constexpr uint32_t BREADTH_FIRST_NODES = 1024;
     const uint32_t n = bvh.n_nodes;
     if (n == 0) return;
-    auto child = [&](uint32_t node, int side) {
+    auto child = [&](uint32_t node, int k) {
         uint32_t r;
-        std::memcpy(&r, &bvh.nodes[16 * (size_t)node + 12 + side], 4);
+        std::memcpy(&r, &bvh.nodes[NODE_FLOATS * (size_t)node + NODE_REFS_AT + k], 4);
         return r;
     };
     std::vector<uint32_t> order;  // order[new] = old
@@ -172,8 +260,8 @@ static void renumber(FlatBvh& bvh) {
     while (head < frontier.size() && order.size() < BREADTH_FIRST_NODES) {
         uint32_t node = frontier[head++];
         order.push_back(node);
-        for (int side = 0; side < 2; ++side) {
-            uint32_t r = child(node, side);
+        for (int k = 0; k < BVH_WIDTH; ++k) {
+            uint32_t r = child(node, k);
             if (!(r & 0x80000000u)) frontier.push_back(r);
         }
     }
@@ -184,24 +272,25 @@ static void renumber(FlatBvh& bvh) {
             uint32_t node = stack.back();
             stack.pop_back();
             order.push_back(node);
-            uint32_t l = child(node, 0), r = child(node, 1);
-            if (!(r & 0x80000000u)) stack.push_back(r);
-            if (!(l & 0x80000000u)) stack.push_back(l);
+            for (int k = BVH_WIDTH - 1; k >= 0; --k) {
+                uint32_t r = child(node, k);
+                if (!(r & 0x80000000u)) stack.push_back(r);
+            }
         }
     }
     std::vector<uint32_t> new_of(n);
     for (uint32_t i = 0; i < (uint32_t)order.size(); ++i) new_of[order[i]] = i;
     std::vector<float> out(bvh.nodes.size());
     for (uint32_t i = 0; i < (uint32_t)order.size(); ++i) {
-        const float* src = &bvh.nodes[16 * (size_t)order[i]];
-        float* dst = &out[16 * (size_t)i];
-        std::memcpy(dst, src, 64);
-        for (int side = 0; side < 2; ++side) {
+        const float* src = &bvh.nodes[NODE_FLOATS * (size_t)order[i]];
+        float* dst = &out[NODE_FLOATS * (size_t)i];
+        std::memcpy(dst, src, NODE_FLOATS * sizeof(float));
+        for (int k = 0; k < BVH_WIDTH; ++k) {
             uint32_t r;
-            std::memcpy(&r, &src[12 + side], 4);
+            std::memcpy(&r, &src[NODE_REFS_AT + k], 4);
             if (!(r & 0x80000000u)) {
                 r = new_of[r];
-                std::memcpy(&dst[12 + side], &r, 4);
+                std::memcpy(&dst[NODE_REFS_AT + k], &r, 4);
             }
         }
     }
@@ -246,6 +335,7 @@ FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads) {
     out.root = root;
     out.n_nodes = bld.next_node.load();
     out.max_depth = bld.max_depth.load();
+    if (BVH_WIDTH == 4) fold_to_four(out);
     renumber(out);
     return out;
 }

@@ -14,9 +14,19 @@ struct BuildPrim {
     uint32_t exact;   // 1: store the box as given (the reference's own leaf AABB); 0: widen it a little
 };
 
-// 16 floats per node, layout documented in rt_device.h.
+// Children per node of the tree the kernels walk.  The builder always makes a binary tree first
+// (binned SAH); for width 4 every other level is then folded into its parent.
+#ifndef RT_BVH_WIDTH
+#define RT_BVH_WIDTH 4
+#endif
+constexpr int BVH_WIDTH = RT_BVH_WIDTH;
+static_assert(BVH_WIDTH == 2 || BVH_WIDTH == 4, "the BVH has 2 or 4 children per node");
+constexpr int NODE_FLOATS = 8 * BVH_WIDTH;          // layout documented in rt_device.h
+constexpr int NODE_REFS_AT = 6 * BVH_WIDTH;         // float index of the first child reference
+constexpr int NODE_SLACK_AT = 7 * BVH_WIDTH;        // float index of the first child's slack factor (an empty slot has slack 0)
+
 struct FlatBvh {
-    std::vector<float> nodes;  // 16 * n_nodes
+    std::vector<float> nodes;  // NODE_FLOATS * n_nodes
     uint32_t root = 0xFFFFFFFFu;
     uint32_t n_nodes = 0;
     uint32_t max_depth = 0;

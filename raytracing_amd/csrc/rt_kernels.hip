@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "rt_bvh.h"
 #include "rt_device.h"
 #include "rt_kernels.h"
 
@@ -298,6 +299,7 @@ struct NodeSource {
     uint32_t n_top;
 };
 typedef float float2v __attribute__((ext_vector_type(2)));
+static constexpr uint32_t NODE_FLOAT4S = NODE_FLOATS / 4;
 
 // One inner node: slab-tests both children, continues with the nearer one and stacks the
 // other.  Returns the next reference (inner node, leaf, or REF_DONE).
@@ -308,6 +310,7 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // (inner node, placed leaf, medium) has its exit distance widened by the node's slack factor;
 // the box of a leaf that sits in world space is the reference's own AABB and is tested with
 // slack 1, so the same leaves get tested as in the reference.
+#if RT_BVH_WIDTH == 2
 template <bool COUNT, bool LDS_TOP, class Stack>
 RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr) {
     if (COUNT) pr.nodes++;
@@ -343,6 +346,56 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
     if (hr) return right;
     return pop_next(st, tmax);
 }
+#else
+// Four children per node.  Each child's slab test is the two-child one above; the children that
+// are hit are ordered by entry distance with a five-exchange sorting network (entry distances
+// are positive, so their bit patterns order like the numbers; a child that is missed gets the
+// key ~0), the nearest is continued with and the others are stacked farthest first.
+RT_D void order2(uint32_t& ka, uint32_t& ra, uint32_t& kb, uint32_t& rb) {
+    const bool swap = kb < ka;
+    const uint32_t k0 = swap ? kb : ka, k1 = swap ? ka : kb, r0 = swap ? rb : ra, r1 = swap ? ra : rb;
+    ka = k0; kb = k1; ra = r0; rb = r1;
+}
+template <bool COUNT, bool LDS_TOP, class Stack>
+RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr) {
+    if (COUNT) pr.nodes++;
+    float4 q[8];
+    if (LDS_TOP && cur < src.n_top) {
+        const lds_float4v* n = (const lds_float4v*)src.top + 8 * cur;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = f4(n[i]);
+    } else {
+        const float4* n = src.nodes + 8 * (size_t)cur;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = n[i];
+    }
+    const float2v oxy = {r.o.x, r.o.y}, ixy = {r.inv.x, r.inv.y}, ozz = {r.o.z, r.o.z}, izz = {r.inv.z, r.inv.z};
+    const float zs[8] = {q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w};
+    const uint32_t refs[4] = {__float_as_uint(q[6].x), __float_as_uint(q[6].y), __float_as_uint(q[6].z), __float_as_uint(q[6].w)};
+    const float slack[4] = {q[7].x, q[7].y, q[7].z, q[7].w};
+    uint32_t key[4], ref[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // NaNs (0 * inf) drop out of fminf/fmaxf, as they do out of simd_min/simd_max in the reference
+        const float2v lo = (float2v{q[k].x, q[k].y} - oxy) * ixy, hi = (float2v{q[k].z, q[k].w} - oxy) * ixy;
+        const float2v z = (float2v{zs[2 * k], zs[2 * k + 1]} - ozz) * izz;
+        const float t_in = fmaxf(fmaxf(fminf(lo.x, hi.x), fminf(lo.y, hi.y)), fmaxf(fminf(z.x, z.y), r.tmin));
+        const float t_out = fminf(fminf(fmaxf(lo.x, hi.x), fmaxf(lo.y, hi.y)), fminf(fmaxf(z.x, z.y), tmax));
+        key[k] = t_in <= t_out * slack[k] ? __float_as_uint(t_in) : 0xFFFFFFFFu;  // slack 0: empty slot
+        ref[k] = refs[k];
+    }
+    order2(key[0], ref[0], key[1], ref[1]);
+    order2(key[2], ref[2], key[3], ref[3]);
+    order2(key[0], ref[0], key[2], ref[2]);
+    order2(key[1], ref[1], key[3], ref[3]);
+    order2(key[1], ref[1], key[2], ref[2]);
+    if (key[0] == 0xFFFFFFFFu) return pop_next(st, tmax);
+    if (key[3] != 0xFFFFFFFFu) st.push(ref[3], __uint_as_float(key[3]));
+    if (key[2] != 0xFFFFFFFFu) st.push(ref[2], __uint_as_float(key[2]));
+    if (key[1] != 0xFFFFFFFFu) st.push(ref[1], __uint_as_float(key[1]));
+    return ref[0];
+}
+#endif
 
 // One leaf: primitive or medium test; a hit shrinks tmax.  Returns the next reference.
 template <bool COUNT, class Stack, class Key>
@@ -832,7 +885,7 @@ static constexpr int EXTEND_BLOCK = 256;
 // enough to be copied into LDS whole - on 8 stack levels and the tree (a copy of only the top
 // levels of a larger tree does not pay: those nodes are served by the L1 cache anyway, and
 // more LDS per block means fewer resident waves).
-static constexpr int SMALL_TREE_NODES = 128;
+static constexpr int SMALL_TREE_NODES = 128 / (RT_BVH_WIDTH / 2);  // 8 KiB of nodes
 template <bool SMALL_TREE> struct ExtendLds {
     static constexpr int STACK_LEVELS = SMALL_TREE ? 8 : 12;
     static constexpr int TOP_NODES = SMALL_TREE ? SMALL_TREE_NODES : 0;
@@ -850,15 +903,17 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(RT
                                                          DCounters* counters) {
     constexpr int LDS_STACK = ExtendLds<SMALL_TREE>::STACK_LEVELS, LDS_TOP_NODES = ExtendLds<SMALL_TREE>::TOP_NODES;
     __shared__ unsigned long long s_stack[EXTEND_BLOCK / 64][LDS_STACK][64];
-    __shared__ float4 s_top[LDS_TOP_NODES > 0 ? 4 * LDS_TOP_NODES : 1];
+    __shared__ float4 s_top[LDS_TOP_NODES > 0 ? NODE_FLOAT4S * LDS_TOP_NODES : 1];
     NodeSource src{sc.nodes, s_top, 0};
     if (LDS_TOP_NODES > 0) {  // the block's copy of the tree
         src.n_top = min(sc.n_nodes, (uint32_t)LDS_TOP_NODES);
-        for (uint32_t i = threadIdx.x; i < 4 * src.n_top; i += EXTEND_BLOCK) s_top[i] = sc.nodes[i];
+        for (uint32_t i = threadIdx.x; i < NODE_FLOAT4S * src.n_top; i += EXTEND_BLOCK) s_top[i] = sc.nodes[i];
         __syncthreads();
     }
     const uint32_t n = counts[bounce];
-    const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    // the same value in all lanes of a wave: said so explicitly, which keeps the queue bookkeeping below in scalar registers
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t wave = blockIdx.x * (EXTEND_BLOCK / 64) + wave_in_block, n_waves = gridDim.x * (EXTEND_BLOCK / 64);
     // Work of this wave: the 64-ray blocks w, w + n_waves, w + 2 n_waves, ... of the queue.  Interleaving
     // spreads expensive image regions over all waves (a contiguous slice per wave does not: the rows of

@@ -250,7 +250,7 @@ def test_two_pipelines_give_the_same_image_as_one():
     one.render_samples(spp)
     assert np.array_equal(one.accumulator(), two.accumulator())
     info = two.info()
-    assert info["bvh_nodes"] + 1 == info["leaves_in_tree"] and info["device_bytes"] > 0
+    assert 0 < info["bvh_nodes"] < info["leaves_in_tree"] and info["device_bytes"] > 0
 
 
 def test_camera_entry_points_and_finalize():
