@@ -782,6 +782,25 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     if ((e = upload(sc, medium_meta, &sc->d.medium_meta))) return bail(e);
     if ((e = upload(sc, boundary_refs, &sc->d.boundary_refs))) return bail(e);
     if ((e = upload(sc, xforms, &sc->d.xforms))) return bail(e);
+    {   // per-leaf copies of the placements, for the kinds that have placed leaves
+        auto per_leaf = [&](size_t n, auto transform_of, const float4** out) -> int {
+            *out = nullptr;
+            bool any = false;
+            for (size_t i = 0; i < n && !any; ++i) any = transform_of(i) != RT_NO_TRANSFORM;
+            if (!any) return RT_OK;
+            std::vector<float4> copy(2 * n, make_float4(0.0f, 1.0f, 0.0f, 0.0f));
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t t = transform_of(i);
+                if (t == RT_NO_TRANSFORM) continue;
+                copy[2 * i] = xforms[2 * (size_t)t];
+                copy[2 * i + 1] = xforms[2 * (size_t)t + 1];
+            }
+            return upload(sc, copy, out);
+        };
+        if ((e = per_leaf(desc->n_spheres, [&](size_t i) { return desc->spheres[i].transform; }, &sc->d.sphere_xf))) return bail(e);
+        if ((e = per_leaf(desc->n_moving_spheres, [&](size_t i) { return desc->moving_spheres[i].transform; }, &sc->d.moving_xf))) return bail(e);
+        if ((e = per_leaf(desc->n_quads, [&](size_t i) { return desc->quads[i].transform; }, &sc->d.quad_xf))) return bail(e);
+    }
     if ((e = upload(sc, materials, &sc->d.materials))) return bail(e);
     if ((e = upload(sc, textures, &sc->d.textures))) return bail(e);
 

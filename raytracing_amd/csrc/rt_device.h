@@ -51,7 +51,7 @@ RT_HD bool ref_placed(uint32_t r) { return (r & REF_PLACED) != 0; }
 //           one 32-byte read: material, prim_id, transform (or RT_NO_TRANSFORM),
 //           class | material kind << 8 | texture kind << 16  ||  bits(param), bits(r, g, b of a
 //           solid-colour texture)
-//   xforms  2 x float4 per placement: sin, cos, 0, 0 | offset.xyz, 0
+//   xforms  2 x float4 per placement: sin, cos, 0, 0 | offset.xyz, 0; *_xf: the same per leaf
 // A leaf wrapped in Move/RotateY stays in object space; the ray is taken into
 // object space at the leaf exactly as Ray::hit_anything does (src/math/ray.rs:207-247),
 // which keeps hit distances bit-identical to the reference's.  Its BVH box is
@@ -107,6 +107,11 @@ struct DScene {
     const uint4* medium_meta;
     const uint32_t* boundary_refs;
     const float4* xforms;      // 2 x float4 per placement
+    // the placement of leaf i once more at [2 i], [2 i + 1] (NULL when no leaf of the kind is placed):
+    // a leaf test reads it together with the primitive instead of after it
+    const float4* sphere_xf;
+    const float4* moving_xf;
+    const float4* quad_xf;
     const DMaterial* materials;
     const DTexture* textures;
     const DImage* images;

@@ -81,12 +81,14 @@ struct Probe {  // per-thread work counters (only live in the counting build)
 
 // Move { RotateY { obj } } entry (src/math/ray.rs:207-229): origin - offset, then
 // x' = cos*x - sin*z, z' = sin*x + cos*z for origin and direction.
-RT_D void ray_to_object(const DScene& sc, uint32_t xf, float3& o, float3& d) {
-    float4 rot = sc.xforms[2 * (size_t)xf], off = sc.xforms[2 * (size_t)xf + 1];
+RT_D void ray_to_object(float4 rot, float4 off, float3& o, float3& d) {
     float s = rot.x, c = rot.y;
     float3 o1 = o - f3(off);
     o = f3((c * o1.x) - (s * o1.z), o1.y, (s * o1.x) + (c * o1.z));
     d = f3((c * d.x) - (s * d.z), d.y, (s * d.x) + (c * d.z));
+}
+RT_D void ray_to_object(const DScene& sc, uint32_t xf, float3& o, float3& d) {
+    ray_to_object(sc.xforms[2 * (size_t)xf], sc.xforms[2 * (size_t)xf + 1], o, d);
 }
 // The way back for a hit record (src/math/ray.rs:75-105): rotate point and normal,
 // then add the offset to the point.
@@ -104,7 +106,7 @@ RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float ti
         if (COUNT) pr.spheres++;
         float4 s = sc.spheres[idx];
         if (ref_placed(ref)) {
-            ray_to_object(sc, sc.sphere_meta[2 * (size_t)idx].z, o, d);
+            ray_to_object(sc.sphere_xf[2 * (size_t)idx], sc.sphere_xf[2 * (size_t)idx + 1], o, d);
             a = dot3(d, d);
         }
         return sphere_root(f3(s), s.w, o, d, a, tmin, tmax, t);
@@ -112,7 +114,7 @@ RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float ti
         if (COUNT) pr.spheres++;
         float4 s0 = sc.moving[2 * (size_t)idx], s1 = sc.moving[2 * (size_t)idx + 1];
         if (ref_placed(ref)) {
-            ray_to_object(sc, sc.moving_meta[2 * (size_t)idx].z, o, d);
+            ray_to_object(sc.moving_xf[2 * (size_t)idx], sc.moving_xf[2 * (size_t)idx + 1], o, d);
             a = dot3(d, d);
         }
         float3 c = f3(s0) + time * f3(s1);  // MovingSphere::hit, src/hittable.rs:310
@@ -120,7 +122,7 @@ RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float ti
     } else {
         if (COUNT) pr.quads++;
         const float4* q4 = sc.quads + 4 * (size_t)idx;
-        if (ref_placed(ref)) ray_to_object(sc, __float_as_uint(q4[3].w), o, d);
+        if (ref_placed(ref)) ray_to_object(sc.quad_xf[2 * (size_t)idx], sc.quad_xf[2 * (size_t)idx + 1], o, d);
         return quad_root(q4, o, d, tmin, tmax, t);
     }
 }
