@@ -196,7 +196,7 @@ def main():
             "roofline": roofline,
             "scene": scene.info(),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the host cores are timed on single-GPU runs only
             result["cpu_baseline"] = cpu_baseline(args.cpu_spp)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
     if world > 1:
