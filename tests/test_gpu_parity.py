@@ -9,7 +9,8 @@ Tolerances (stated here once, used below):
     image <= 1e-3 and >= 99 % of the pixels within 1e-4 relative.
   * per image, reference random numbers (per-row xoshiro) against the GPU's: the two are
     different Monte-Carlo estimates of one image; RMSE(GPU, CPU) <= 1.15 * RMSE(CPU, CPU')
-    at equal sample counts and image means within 3 sigma of the noise + 0.5 %.
+    at equal sample counts and image means within 3 sigma of the noise + 0.5 %; at 2048 samples
+    per pixel (Book-1 scene) additionally RMSE <= 0.01 absolute.
 """
 import os
 
@@ -126,6 +127,22 @@ def test_image_statistics_match_reference_random_numbers(sid, spp):
         a, b, c = cpu_a[..., ch].mean() / spp, cpu_b[..., ch].mean() / spp, gpu[..., ch].mean() / spp
         ref = 0.5 * (a + b)
         assert abs(c - ref) <= 3.0 * abs(a - b) + 0.005 * ref + 1e-6, (ch, a, b, c)
+
+
+def test_high_sample_count_image_rmse():
+    """Book-1 scene, 2048 samples per pixel on both sides (reference random numbers on the CPU): the sqrt-encoded
+    images agree to an absolute RMSE of 0.01 and no worse than two CPU renders agree with each other."""
+    w = h = 24
+    spp = 2048
+    scene = rt.Scene.builtin(0, w, h)
+    oracle = ob.OracleScene.builtin(0, w, h)
+    scene.render_samples(spp)
+    gpu = scene.accumulator()[:, 4:]
+    cpu_a = oracle.render(spp, first_sample=1, mode=ob.RNG_XOSHIRO)[:, 4:]
+    cpu_b = oracle.render(spp, first_sample=spp + 1, mode=ob.RNG_XOSHIRO)[:, 4:]
+    noise = np.sqrt(np.mean((enc(cpu_a, spp) - enc(cpu_b, spp)) ** 2))
+    rmse = np.sqrt(np.mean((enc(gpu, spp) - enc(cpu_a, spp)) ** 2))
+    assert rmse <= 0.01 and rmse <= 1.15 * noise, (rmse, noise)
 
 
 def _random_scene(s, rng):
