@@ -888,8 +888,11 @@ static constexpr int EXTEND_BLOCK = 256;
 // levels of a larger tree does not pay: those nodes are served by the L1 cache anyway, and
 // more LDS per block means fewer resident waves).
 static constexpr int SMALL_TREE_NODES = 128 / (RT_BVH_WIDTH / 2);  // 8 KiB of nodes
+#ifndef RT_EXTEND_STACK
+#define RT_EXTEND_STACK 12  // stack levels per lane kept in LDS (large trees)
+#endif
 template <bool SMALL_TREE> struct ExtendLds {
-    static constexpr int STACK_LEVELS = SMALL_TREE ? 8 : 12;
+    static constexpr int STACK_LEVELS = SMALL_TREE ? 8 : RT_EXTEND_STACK;
     static constexpr int TOP_NODES = SMALL_TREE ? SMALL_TREE_NODES : 0;
 };
 static constexpr int MIN_LDS_STACK = 8;
@@ -1457,7 +1460,7 @@ int extend_blocks_per_cu(bool counting) {
     a = std::min(a, b);
     (void)hipGetLastError();
     // a block whose LDS divides the CU's 160 KiB exactly does not get the last slot in practice
-    int by_lds = (int)((160u * 1024u - 1024u) / (24u * 1024u + 16u));  // both variants: 24 KiB per block
+    int by_lds = (int)((160u * 1024u - 1024u) / (2048u * (uint32_t)RT_EXTEND_STACK + 16u));  // 2 KiB per stack level and block
     return std::min(a, by_lds);
 }
 // bytes of the extend kernel's stack overflow area for a grid of `blocks` blocks
