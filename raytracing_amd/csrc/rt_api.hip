@@ -924,53 +924,62 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
         for (int i = 0; i < n_pipes; ++i) HIP_TRY(hipStreamWaitEvent(c->pipes[i].stream, c->ev_begin, 0));
     uint32_t batch_no = 0;
     Pipe* prev = nullptr;
-    for (uint64_t p0 = 0; p0 < npix; p0 += chunk_pixels) {
-        const uint32_t np = (uint32_t)std::min<uint64_t>(chunk_pixels, npix - p0);
-        for (uint32_t s0 = 0; s0 < n_samples; s0 += spb, ++batch_no) {
-            const uint32_t ns = std::min(spb, n_samples - s0);
-            BatchInfo b{(uint32_t)p0, np, first_sample + s0, ns};
-            const uint32_t total = np * ns;
-            Pipe& q = c->pipes[batch_no % (uint32_t)n_pipes];
-            hipStream_t st = n_pipes > 1 ? q.stream : c->stream;
-            EventPair* ep;
-            if ((e = phase_begin(c, st, 0, &ep))) return e;
-            // leaves kept out of the tree: tested by ray generation for the camera rays (by the counting pass when
-            // the work counters are on), by a pass of their own for the rays shade creates
-            const bool raygen_first_leaves = sc->d.n_global != 0 && counters == nullptr;
-            launch_raygen(st, c->max_blocks, sc->d, dcam, b, seed, q.ray_o[0], q.ray_d[0], q.thr[0], raygen_first_leaves ? q.hits : nullptr,
-                          q.counts, n_counts);
-            if ((e = phase_end(st, ep))) return e;
-            int cur = 0;
-            for (uint32_t bounce = 0; bounce < cam->max_depth; ++bounce) {
-                if (sc->d.n_global != 0 && !(bounce == 0 && raygen_first_leaves)) {
-                    if ((e = phase_begin(c, st, 4, &ep))) return e;
-                    launch_first_leaves(st, c->max_blocks, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur], q.ray_d[cur], q.hits, counters);
+    // all launches of the call; whatever it returns, the pipelines' streams are joined to the caller's afterwards
+    auto enqueue = [&]() -> int {
+        for (uint64_t p0 = 0; p0 < npix; p0 += chunk_pixels) {
+            const uint32_t np = (uint32_t)std::min<uint64_t>(chunk_pixels, npix - p0);
+            for (uint32_t s0 = 0; s0 < n_samples; s0 += spb, ++batch_no) {
+                const uint32_t ns = std::min(spb, n_samples - s0);
+                BatchInfo b{(uint32_t)p0, np, first_sample + s0, ns};
+                const uint32_t total = np * ns;
+                Pipe& q = c->pipes[batch_no % (uint32_t)n_pipes];
+                hipStream_t st = n_pipes > 1 ? q.stream : c->stream;
+                EventPair* ep;
+                if ((e = phase_begin(c, st, 0, &ep))) return e;
+                // leaves kept out of the tree: tested by ray generation for the camera rays (by the counting pass when
+                // the work counters are on), by a pass of their own for the rays shade creates
+                const bool raygen_first_leaves = sc->d.n_global != 0 && counters == nullptr;
+                launch_raygen(st, c->max_blocks, sc->d, dcam, b, seed, q.ray_o[0], q.ray_d[0], q.thr[0], raygen_first_leaves ? q.hits : nullptr,
+                              q.counts, n_counts);
+                if ((e = phase_end(st, ep))) return e;
+                int cur = 0;
+                for (uint32_t bounce = 0; bounce < cam->max_depth; ++bounce) {
+                    if (sc->d.n_global != 0 && !(bounce == 0 && raygen_first_leaves)) {
+                        if ((e = phase_begin(c, st, 4, &ep))) return e;
+                        launch_first_leaves(st, c->max_blocks, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur], q.ray_d[cur], q.hits, counters);
+                        if ((e = phase_end(st, ep))) return e;
+                    }
+                    if ((e = phase_begin(c, st, 1, &ep))) return e;
+                    launch_extend(st, counters ? c->extend_blocks_counting : c->extend_blocks, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur],
+                                  q.ray_d[cur], q.hits, q.stack_overflow, c->tune, counters);
                     if ((e = phase_end(st, ep))) return e;
+                    if ((e = phase_begin(c, st, 2, &ep))) return e;
+                    launch_shade(st, c->max_blocks, total, sc->d, dcam, b, seed, bounce, q.counts, q.counts + n_queue_counts + bounce, q.tex_list,
+                                 q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.hits, q.ray_o[cur ^ 1], q.ray_d[cur ^ 1], q.thr[cur ^ 1], q.radiance,
+                                 sc->has_textures);
+                    if ((e = phase_end(st, ep))) return e;
+                    cur ^= 1;
                 }
-                if ((e = phase_begin(c, st, 1, &ep))) return e;
-                launch_extend(st, counters ? c->extend_blocks_counting : c->extend_blocks, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur],
-                              q.ray_d[cur], q.hits, q.stack_overflow, c->tune, counters);
+                if (cam->max_depth == 0) HIP_TRY(hipMemsetAsync(q.radiance, 0, (size_t)total * sizeof(float4), st));
+                // the accumulation buffer takes the batches in their order: sample sums stay bit-identical
+                // to a one-pipeline render
+                if (n_pipes > 1 && prev && prev != &q) HIP_TRY(hipStreamWaitEvent(st, prev->done, 0));
+                if ((e = phase_begin(c, st, 3, &ep))) return e;
+                launch_accumulate(st, c->max_blocks, b, q.radiance, (float4*)d_acc);
                 if ((e = phase_end(st, ep))) return e;
-                if ((e = phase_begin(c, st, 2, &ep))) return e;
-                launch_shade(st, c->max_blocks, total, sc->d, dcam, b, seed, bounce, q.counts, q.counts + n_queue_counts + bounce, q.tex_list,
-                             q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.hits, q.ray_o[cur ^ 1], q.ray_d[cur ^ 1], q.thr[cur ^ 1], q.radiance,
-                             sc->has_textures);
-                if ((e = phase_end(st, ep))) return e;
-                cur ^= 1;
+                if (n_pipes > 1) HIP_TRY(hipEventRecord(q.done, st));
+                prev = &q;
             }
-            if (cam->max_depth == 0) HIP_TRY(hipMemsetAsync(q.radiance, 0, (size_t)total * sizeof(float4), st));
-            // the accumulation buffer takes the batches in their order: sample sums stay bit-identical
-            // to a one-pipeline render
-            if (n_pipes > 1 && prev && prev != &q) HIP_TRY(hipStreamWaitEvent(st, prev->done, 0));
-            if ((e = phase_begin(c, st, 3, &ep))) return e;
-            launch_accumulate(st, c->max_blocks, b, q.radiance, (float4*)d_acc);
-            if ((e = phase_end(st, ep))) return e;
-            if (n_pipes > 1) HIP_TRY(hipEventRecord(q.done, st));
-            prev = &q;
         }
+        return RT_OK;
+    };
+    const int enqueued = enqueue();
+    if (n_pipes > 1) {
+        if (enqueued != RT_OK)  // a batch was cut short: its pipeline's stream still has to be waited for
+            for (int i = 0; i < n_pipes; ++i) (void)hipEventRecord(c->pipes[i].done, c->pipes[i].stream);
+        for (int i = 0; i < n_pipes && (enqueued != RT_OK || i < (int)batch_no); ++i) HIP_TRY(hipStreamWaitEvent(c->stream, c->pipes[i].done, 0));
     }
-    if (n_pipes > 1)
-        for (int i = 0; i < n_pipes && i < (int)batch_no; ++i) HIP_TRY(hipStreamWaitEvent(c->stream, c->pipes[i].done, 0));
+    if (enqueued != RT_OK) return enqueued;
     HIP_TRY(hipEventRecord(c->ev_end, c->stream));
     HIP_TRY(hipGetLastError());
     c->have_render_time = true;
