@@ -321,6 +321,23 @@ typedef struct rt_scene_info {
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 
+/* The host-side tree builder on its own (no GPU involved): builds the tree that
+ * rt_scene_create would build over `n` leaf boxes (min.xyz, max.xyz per leaf,
+ * 6 floats each) and checks it: every leaf referenced exactly once, every box
+ * of an inner child covering the boxes beneath it, references in range, nodes
+ * numbered parents first.  Replaces nothing in the reference (its
+ * Hittable::bvh, src/hittable.rs:103-155, is checked only by rendering); it is
+ * here so that the builder can be tested where there is no GPU. */
+typedef struct rt_bvh_report {
+    uint32_t nodes;
+    uint32_t depth;
+    uint32_t width;            /* children per node */
+    uint32_t leaves_found;     /* distinct leaves reachable from the root */
+    uint32_t violations;       /* 0 for a correct tree */
+    float sah_cost;            /* sum over inner children and leaves of area / root area */
+} rt_bvh_report;
+int rt_bvh_build_check(const float* boxes, uint32_t n, rt_bvh_report* out);
+
 /* Replaces `n_samples` consecutive calls of RaytracingCamera::render
  * (src/camera.rs:269-306) with sample numbers first_sample,
  * first_sample+1, ... (the reference counts from 1, src/camera.rs:82-83):

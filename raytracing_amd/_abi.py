@@ -55,6 +55,11 @@ class RtSceneInfo(C.Structure):
                 ("leaves_tested_first", C.c_uint32), ("device_bytes", C.c_uint64), ("build_seconds", C.c_double)]
 
 
+class RtBvhReport(C.Structure):
+    _fields_ = [("nodes", C.c_uint32), ("depth", C.c_uint32), ("width", C.c_uint32), ("leaves_found", C.c_uint32),
+                ("violations", C.c_uint32), ("sah_cost", C.c_float)]
+
+
 class Leaf(C.Structure):
     """One leaf of a flattened scene (object-space data plus its placement)."""
     _fields_ = [("kind", C.c_uint32), ("prim_id", C.c_uint32), ("material", C.c_uint32), ("medium", C.c_uint32),
@@ -108,6 +113,7 @@ RT_ABI = {
     "rt_scene_create": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "rt_scene_destroy": (C.c_int, [_P]),
     "rt_scene_get_info": (C.c_int, [_P, C.POINTER(RtSceneInfo)]),
+    "rt_bvh_build_check": (C.c_int, [_FP, _U32, C.POINTER(RtBvhReport)]),
     "rt_render_accumulate": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_render_accumulate_device": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_finalize_device": (C.c_int, [_P, _P, _U64, _U32, C.c_int, _F, _P]),

@@ -871,6 +871,80 @@ int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
     return RT_OK;
 }
 
+int rt_bvh_build_check(const float* boxes, uint32_t n, rt_bvh_report* out) {
+    if (!out || (n && !boxes)) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n >= rt::MAX_PRIMS_PER_KIND) return fail(RT_ERR_UNSUPPORTED, "more than 2^28 leaves");
+    std::vector<BuildPrim> prims(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) { prims[i].bmin[a] = boxes[6 * (size_t)i + a]; prims[i].bmax[a] = boxes[6 * (size_t)i + 3 + a]; }
+        prims[i].ref = make_leaf(KIND_SPHERE, i, false);
+        prims[i].exact = 1;
+    }
+    FlatBvh bvh = build_bvh(prims, 0);
+    *out = rt_bvh_report{bvh.n_nodes, bvh.max_depth, (uint32_t)rt::BVH_WIDTH, 0, 0, 0.0f};
+    if (n == 0) { out->violations = bvh.root == REF_NONE ? 0 : 1; return RT_OK; }
+    if (n == 1) { out->leaves_found = 1; out->violations = bvh.root == make_leaf(KIND_SPHERE, 0, false) ? 0 : 1; return RT_OK; }
+    struct Box3 { float mn[3], mx[3]; };
+    auto child_box = [&](uint32_t node, int k) {
+        const float* q = &bvh.nodes[rt::NODE_FLOATS * (size_t)node];
+        Box3 b;
+        b.mn[0] = q[4 * k]; b.mn[1] = q[4 * k + 1]; b.mx[0] = q[4 * k + 2]; b.mx[1] = q[4 * k + 3];
+        b.mn[2] = q[4 * rt::BVH_WIDTH + 2 * k]; b.mx[2] = q[4 * rt::BVH_WIDTH + 2 * k + 1];
+        return b;
+    };
+    auto area = [](const Box3& b) {
+        float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<uint8_t> seen(n, 0);
+    uint32_t violations = 0, found = 0;
+    double cost = 0.0;
+    Box3 root_box{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+    for (uint32_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            root_box.mn[a] = std::min(root_box.mn[a], boxes[6 * (size_t)i + a]);
+            root_box.mx[a] = std::max(root_box.mx[a], boxes[6 * (size_t)i + 3 + a]);
+        }
+    const double root_area = std::max(1e-30, (double)area(root_box));
+    // walk from the root; `bound` is the box the parent stores for this subtree
+    struct Item { uint32_t node; Box3 bound; bool has_bound; };
+    std::vector<Item> todo{{bvh.root, root_box, false}};
+    if (ref_is_leaf(bvh.root) || bvh.root >= bvh.n_nodes) { out->violations = 1; return RT_OK; }
+    std::vector<uint8_t> node_seen(bvh.n_nodes, 0);
+    while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        if (node_seen[it.node]++) { ++violations; continue; }
+        for (int k = 0; k < rt::BVH_WIDTH; ++k) {
+            const float slack = bvh.nodes[rt::NODE_FLOATS * (size_t)it.node + rt::NODE_SLACK_AT + k];
+            if (slack == 0.0f) continue;  // empty slot
+            uint32_t r;
+            std::memcpy(&r, &bvh.nodes[rt::NODE_FLOATS * (size_t)it.node + rt::NODE_REFS_AT + k], 4);
+            Box3 cb = child_box(it.node, k);
+            cost += area(cb) / root_area;
+            if (it.has_bound)
+                for (int a = 0; a < 3; ++a)
+                    if (cb.mn[a] < it.bound.mn[a] - 1e-3f * (1.0f + std::fabs(it.bound.mn[a])) || cb.mx[a] > it.bound.mx[a] + 1e-3f * (1.0f + std::fabs(it.bound.mx[a]))) ++violations;
+            if (ref_is_leaf(r)) {
+                uint32_t idx = ref_index(r);
+                if (ref_kind(r) != KIND_SPHERE || idx >= n || seen[idx]++) { ++violations; continue; }
+                ++found;
+                if (slack != 1.0f) ++violations;  // a leaf given as exact keeps its own box, tested without slack
+                for (int a = 0; a < 3; ++a)
+                    if (cb.mn[a] != boxes[6 * (size_t)idx + a] || cb.mx[a] != boxes[6 * (size_t)idx + 3 + a]) ++violations;
+            } else {
+                if (r >= bvh.n_nodes || r <= it.node) { ++violations; continue; }  // parents are numbered before their children
+                todo.push_back(Item{r, cb, true});
+            }
+        }
+    }
+    for (uint32_t i = 0; i < bvh.n_nodes; ++i) if (!node_seen[i]) ++violations;
+    out->leaves_found = found;
+    out->violations = violations + (found != n ? 1u : 0u);
+    out->sah_cost = (float)cost;
+    return RT_OK;
+}
+
 int rt_scene_destroy(rt_scene* sc) {
     if (!sc) return RT_OK;
     (void)hipSetDevice(sc->ctx->device);
