@@ -335,6 +335,8 @@ typedef struct rt_bvh_report {
     uint32_t leaves_found;     /* distinct leaves reachable from the root */
     uint32_t violations;       /* 0 for a correct tree */
     float sah_cost;            /* sum over inner children and leaves of area / root area */
+    uint32_t stack_need;       /* traversal stack entries needed in the worst case (rt_scene_create accepts <= 64) */
+    uint32_t _pad;
 } rt_bvh_report;
 int rt_bvh_build_check(const float* boxes, uint32_t n, rt_bvh_report* out);
 

@@ -57,7 +57,7 @@ class RtSceneInfo(C.Structure):
 
 class RtBvhReport(C.Structure):
     _fields_ = [("nodes", C.c_uint32), ("depth", C.c_uint32), ("width", C.c_uint32), ("leaves_found", C.c_uint32),
-                ("violations", C.c_uint32), ("sah_cost", C.c_float)]
+                ("violations", C.c_uint32), ("sah_cost", C.c_float), ("stack_need", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class Leaf(C.Structure):

@@ -731,7 +731,9 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         prims.push_back(bp);
     }
     FlatBvh bvh = build_bvh(prims, 0);
-    if (bvh.max_depth > 62) return fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.max_depth);
+    if (bvh.stack_need > rt::TRAVERSAL_STACK_ENTRIES)
+        return fail(RT_ERR_UNSUPPORTED, "the tree (depth %u) can need %u traversal stack entries, %u are available", bvh.max_depth,
+                    bvh.stack_need, rt::TRAVERSAL_STACK_ENTRIES);
     {   // every reference the kernels will follow must point inside its array
         auto ref_ok = [&](uint32_t r) {
             if (!ref_is_leaf(r)) return r < bvh.n_nodes;
@@ -881,7 +883,7 @@ int rt_bvh_build_check(const float* boxes, uint32_t n, rt_bvh_report* out) {
         prims[i].exact = 1;
     }
     FlatBvh bvh = build_bvh(prims, 0);
-    *out = rt_bvh_report{bvh.n_nodes, bvh.max_depth, (uint32_t)rt::BVH_WIDTH, 0, 0, 0.0f};
+    *out = rt_bvh_report{bvh.n_nodes, bvh.max_depth, (uint32_t)rt::BVH_WIDTH, 0, 0, 0.0f, bvh.stack_need, 0};
     if (n == 0) { out->violations = bvh.root == REF_NONE ? 0 : 1; return RT_OK; }
     if (n == 1) { out->leaves_found = 1; out->violations = bvh.root == make_leaf(KIND_SPHERE, 0, false) ? 0 : 1; return RT_OK; }
     struct Box3 { float mn[3], mx[3]; };

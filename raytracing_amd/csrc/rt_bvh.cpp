@@ -296,6 +296,19 @@ static void renumber(FlatBvh& bvh) {
     }
     bvh.nodes.swap(out);
     bvh.root = new_of[bvh.root];
+    // worst-case stack use; children have larger numbers than their parents, so one backward pass does it
+    std::vector<uint32_t> need(n, 0);
+    for (uint32_t i = n; i-- > 0;) {
+        uint32_t children = 0, deepest = 0;
+        for (int k = 0; k < BVH_WIDTH; ++k) {
+            if (bvh.nodes[NODE_FLOATS * (size_t)i + NODE_SLACK_AT + k] == 0.0f) continue;
+            ++children;
+            uint32_t r = child(i, k);
+            if (!(r & 0x80000000u)) deepest = std::max(deepest, need[r]);
+        }
+        need[i] = (children ? children - 1 : 0) + deepest;
+    }
+    bvh.stack_need = need[bvh.root];
 }
 
 FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads) {

@@ -30,7 +30,12 @@ struct FlatBvh {
     uint32_t root = 0xFFFFFFFFu;
     uint32_t n_nodes = 0;
     uint32_t max_depth = 0;
+    // Entries a near-child-first traversal can have stacked at once in the worst case (every child of every node
+    // on a root-to-leaf path is hit): max over such paths of the sum of (children - 1).
+    uint32_t stack_need = 0;
 };
+// What the kernels' traversal stacks hold (LDS part + overflow area, or the per-lane array of the record entry points).
+constexpr uint32_t TRAVERSAL_STACK_ENTRIES = 64;
 
 // Builds over `prims` (reordered in place).  threads <= 0 picks a default.
 FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads);

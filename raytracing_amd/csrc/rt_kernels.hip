@@ -33,7 +33,7 @@
 namespace rt {
 
 static constexpr float RT_INF = __builtin_huge_valf();
-static constexpr int STACK_SIZE = 64;
+static constexpr int STACK_SIZE = (int)TRAVERSAL_STACK_ENTRIES;  // rt_scene_create rejects trees that could need more
 
 // ---------------------------------------------------------------------------
 // leaf tests

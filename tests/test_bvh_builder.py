@@ -32,6 +32,8 @@ def test_every_leaf_once_and_boxes_nested(n):
     if n >= 2:
         assert 1 <= rep.nodes <= n - 1
         assert rep.depth <= 40 + 24   # SAH splits, median splits below depth 40
+        assert 1 <= rep.stack_need <= (rep.width - 1) * rep.depth
+        assert rep.stack_need <= 64, "random boxes must fit the traversal stack"
 
 
 def test_degenerate_inputs_still_give_a_valid_tree():
