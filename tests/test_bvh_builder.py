@@ -48,6 +48,16 @@ def test_degenerate_inputs_still_give_a_valid_tree():
     assert check(huge).violations == 0
 
 
+def test_chain_shaped_tree_stays_within_the_traversal_stack():
+    """Boxes that double in size and distance make SAH peel one leaf off per level: the deepest tree f32 coordinates
+    allow.  Its worst-case stack need stays within the 64 entries the kernels have (rt_scene_create checks this number)."""
+    x = np.array([2.0 ** i for i in range(120)])
+    h = 0.25 * x
+    rep = check(np.stack([x - h, -h, -h, x + h, h, h], axis=1))
+    assert rep.violations == 0 and rep.leaves_found == 120
+    assert rep.depth >= 15 and rep.stack_need <= 64
+
+
 def test_sah_tree_is_cheaper_than_a_shuffled_insertion_order_would_suggest():
     """The surface-area cost of the tree does not depend on the order the leaves are handed in."""
     rng = np.random.default_rng(3)
