@@ -1,9 +1,10 @@
 // rt_kernels.hip — gfx950 kernels of the wavefront path tracer.
 //
 // One sample of one pixel is a "path"; a path is advanced one segment per
-// bounce by two kernels that stream compacted queues through HBM:
+// bounce by kernels that stream compacted queues through HBM:
 //
 //   raygen      get_ray (src/camera.rs:311-320,368-380)          -> ray queue
+//   first leaves  the leaves kept out of the tree (scene-sized boxes), for every ray
 //   extend      Ray::hit_anything (src/math/ray.rs:59-275): flattened-BVH closest
 //               hit incl. constant media                          -> hit records
 //   shade       ray_colour's loop body (src/camera.rs:339-364): Material::emitted /
@@ -24,10 +25,9 @@
 #include "rt_device.h"
 #include "rt_kernels.h"
 
-// Leaf tests, ray generation and shading keep the reference's operation order
-// (rustc never fuses a*b+c), so that hit distances and scattered rays agree with
-// the reference's f32 results bit for bit wherever the same inputs are used.
-// Only the BVH slab test, which culls but never decides a result, is contracted.
+// Leaf tests, box tests, ray generation and shading keep the reference's operation
+// order (rustc never fuses a*b+c), so that hit distances and scattered rays agree
+// with the reference's f32 results bit for bit wherever the same inputs are used.
 #pragma clang fp contract(off)
 
 namespace rt {
