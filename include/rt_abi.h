@@ -357,6 +357,15 @@ int rt_render_accumulate(rt_scene* scene, const rt_camera_desc* cam,
 int rt_render_accumulate_device(rt_scene* scene, const rt_camera_desc* cam,
                                 uint64_t seed, uint32_t first_sample,
                                 uint32_t n_samples, float* d_acc);
+/* The same for rows first_row .. first_row + n_rows - 1 of the image only (the
+ * other rows of d_acc, which is still the whole width*height*4 buffer, are not
+ * touched).  Every pixel is rendered wholly by one call, so GPUs that split an
+ * image by rows and sum their buffers get bit for bit the image of one GPU;
+ * the reference's own parallel unit is the row as well (src/camera.rs:282-304). */
+int rt_render_accumulate_rows_device(rt_scene* scene, const rt_camera_desc* cam,
+                                     uint64_t seed, uint32_t first_sample,
+                                     uint32_t n_samples, uint32_t first_row,
+                                     uint32_t n_rows, float* d_acc);
 
 /* Replaces the per-pixel closures of Camera::hdr_render / realtime_render
  * (src/camera.rs:95-100,115-118) and Colour::to_rgba (src/math/vec3.rs:252-259).

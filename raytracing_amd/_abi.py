@@ -116,6 +116,7 @@ RT_ABI = {
     "rt_bvh_build_check": (C.c_int, [_FP, _U32, C.POINTER(RtBvhReport)]),
     "rt_render_accumulate": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_render_accumulate_device": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
+    "rt_render_accumulate_rows_device": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _U32, _U32, _P]),
     "rt_finalize_device": (C.c_int, [_P, _P, _U64, _U32, C.c_int, _F, _P]),
     "rt_finalize": (C.c_int, [_P, _P, _U64, _U32, C.c_int, _F, _P]),
     "rt_intersect_batch": (C.c_int, [_P, _P, C.c_size_t, _U64, _P]),

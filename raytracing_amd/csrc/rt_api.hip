@@ -958,13 +958,22 @@ int rt_scene_destroy(rt_scene* sc) {
 
 int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, uint32_t first_sample, uint32_t n_samples,
                                 float* d_acc) {
+    if (cam == nullptr) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    return rt_render_accumulate_rows_device(sc, cam, seed, first_sample, n_samples, 0, cam->height, d_acc);
+}
+
+int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, uint32_t first_sample, uint32_t n_samples,
+                                     uint32_t first_row, uint32_t n_rows, float* d_acc) {
     if (!sc || !d_acc) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
     int e = check_camera(cam);
     if (e) return e;
     rt_ctx* c = sc->ctx;
     if ((e = set_device(c))) return e;
     if ((uint64_t)first_sample + n_samples > 0xFFFFFFFFull) return fail(RT_ERR_INVALID_ARGUMENT, "sample numbers overflow 32 bits");
-    const uint64_t npix = (uint64_t)cam->width * cam->height;
+    if ((uint64_t)first_row + n_rows > cam->height) return fail(RT_ERR_INVALID_ARGUMENT, "rows %u..%u outside the image of %u rows", first_row, first_row + n_rows, cam->height);
+    if (n_rows == 0) return RT_OK;
+    const uint64_t pix0 = (uint64_t)first_row * cam->width;     // the rows are one contiguous range of pixels
+    const uint64_t npix = (uint64_t)cam->width * n_rows;
     const uint64_t all_paths = npix * (uint64_t)n_samples;
     // one pipeline for small jobs (and for single-sample calls, which are not split)
     const int n_pipes = (c->n_pipes > 1 && n_samples >= 2 && all_paths >= (1ull << 22)) ? c->n_pipes : 1;
@@ -1006,7 +1015,7 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
             const uint32_t np = (uint32_t)std::min<uint64_t>(chunk_pixels, npix - p0);
             for (uint32_t s0 = 0; s0 < n_samples; s0 += spb, ++batch_no) {
                 const uint32_t ns = std::min(spb, n_samples - s0);
-                BatchInfo b{(uint32_t)p0, np, first_sample + s0, ns};
+                BatchInfo b{(uint32_t)(pix0 + p0), np, first_sample + s0, ns};
                 const uint32_t total = np * ns;
                 Pipe& q = c->pipes[batch_no % (uint32_t)n_pipes];
                 hipStream_t st = n_pipes > 1 ? q.stream : c->stream;

@@ -1,4 +1,4 @@
-"""Multi-GPU partitioning of a render: sample slicing + one sum-reduce.
+"""Multi-GPU partitioning of a render: sample slicing (or row slicing) + one sum-reduce.
 
 Every (pixel, sample) is independent (the random numbers are a pure function of
 them), so a render of S samples on N ranks is: rank r renders the contiguous
@@ -18,6 +18,17 @@ def sample_slice(total_samples, rank, world_size, first_sample=1):
     count = base + (1 if rank < extra else 0)
     start = first_sample + rank * base + min(rank, extra)
     return start, count
+
+
+def row_slice(height, rank, world_size):
+    """(first_row, n_rows) of this rank's share of the image rows.  The alternative to sample slicing for calls
+    with few samples (interactive frames): every rank renders all samples of its rows into a zeroed whole-image
+    buffer (`rt_render_accumulate_rows_device`), and the same sum-reduce assembles the image.  Each pixel is summed
+    on one rank only, so the result equals the one-GPU image bit for bit."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    base, extra = divmod(height, world_size)
+    return rank * base + min(rank, extra), base + (1 if rank < extra else 0)
 
 
 def reduce_accumulators(acc, dst=None, group=None):

@@ -328,6 +328,11 @@ class Scene(BuilderCalls):
         cam = self.camera_desc()
         self._check(self.amd.rt_render_accumulate_device(self.rt_scene, C.byref(cam), seed, first_sample, n_samples, d_acc))
 
+    def render_accumulate_rows_device(self, d_acc, first_sample, n_samples, first_row, n_rows, seed=0):
+        """Rows first_row .. first_row + n_rows - 1 only; d_acc is still the whole-image buffer."""
+        cam = self.camera_desc()
+        self._check(self.amd.rt_render_accumulate_rows_device(self.rt_scene, C.byref(cam), seed, first_sample, n_samples, first_row, n_rows, d_acc))
+
     def info(self):
         i = _abi.RtSceneInfo()
         self._check(self.amd.rt_scene_get_info(self.rt_scene, C.byref(i)))

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from raytracing_amd.distributed import sample_slice
+from raytracing_amd.distributed import row_slice, sample_slice
 
 
 def test_sample_slices_partition_the_range():
@@ -23,6 +23,18 @@ def test_sample_slices_partition_the_range():
             assert max(counts) - min(counts) <= 1
     with pytest.raises(ValueError):
         sample_slice(8, 2, 2)
+
+
+def test_row_slices_partition_the_image():
+    for height in (1, 2, 7, 225, 2160):
+        for world in (1, 2, 3, 8):
+            rows = []
+            for r in range(world):
+                first, n = row_slice(height, r, world)
+                rows.extend(range(first, first + n))
+            assert rows == list(range(height))
+    with pytest.raises(ValueError):
+        row_slice(8, -1, 2)
 
 
 def _worker(rank, world, port, out_dir):
@@ -45,6 +57,15 @@ def _worker(rank, world, port, out_dir):
     acc2 = torch.from_numpy(scene.render(count, first_sample=first, seed=21, threads=1))
     reduce_accumulators(acc2, dst=0)      # reduce to rank 0 only
     np.save(os.path.join(out_dir, f"root_{rank}.npy"), acc2.numpy())
+    # row slicing: every rank contributes all samples of its rows, zeros elsewhere
+    from raytracing_amd.distributed import row_slice
+    first_row, n_rows = row_slice(24, rank, world)
+    full = scene.render(7, first_sample=1, seed=21, threads=1)
+    mine = np.zeros_like(full)
+    mine[first_row:first_row + n_rows] = full[first_row:first_row + n_rows]
+    rows = torch.from_numpy(mine)
+    reduce_accumulators(rows)
+    np.save(os.path.join(out_dir, f"rows_{rank}.npy"), rows.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,3 +84,5 @@ def test_two_ranks_sample_slicing_and_reduce(tmp_path):
     # same samples, different summation order: equal up to f32 rounding of the partial sums
     assert np.allclose(a0, whole, rtol=1e-6, atol=1e-6)
     assert np.allclose(np.load(tmp_path / "root_0.npy"), whole, rtol=1e-6, atol=1e-6)
+    # row slicing sums each pixel on one rank: identical to the single-process image
+    assert np.array_equal(np.load(tmp_path / "rows_0.npy"), whole) and np.array_equal(np.load(tmp_path / "rows_1.npy"), whole)

@@ -270,6 +270,33 @@ def test_two_pipelines_give_the_same_image_as_one():
     assert 0 < info["bvh_nodes"] < info["leaves_in_tree"] and info["device_bytes"] > 0
 
 
+def test_rows_rendered_separately_add_up_to_the_whole_image():
+    """Row ranges (the multi-GPU alternative to sample slicing) into zeroed whole-image buffers: their sum is the
+    one-call image bit for bit; rows outside a range are not touched; bad ranges are refused."""
+    import ctypes as C
+    w, h, spp = 96, 50, 3
+    whole = rt.Scene.builtin(8, w, h)
+    whole.set_seed(5)
+    whole.render_samples(spp)
+    ref = whole.accumulator()
+    s = rt.Scene.builtin(8, w, h)
+    n = w * h * 16
+    total = np.zeros_like(ref)
+    for first_row, n_rows in ((0, 17), (17, 1), (18, 32)):
+        d = C.c_void_p()
+        s._check(s.amd.rt_buffer_create(s.ctx, n, C.byref(d)))
+        s._check(s.amd.rt_buffer_zero(s.ctx, d, n))
+        s.render_accumulate_rows_device(d, 1, spp, first_row, n_rows, seed=5)
+        part = np.empty_like(ref)
+        s._check(s.amd.rt_buffer_download(s.ctx, part.ctypes.data, d, n))
+        s._check(s.amd.rt_buffer_destroy(s.ctx, d))
+        assert not part[:first_row].any() and not part[first_row + n_rows:].any()
+        total += part
+    assert np.array_equal(total, ref)
+    with pytest.raises(rt.RenderError):
+        s.render_accumulate_rows_device(s.device_accumulator, 1, 1, 40, 11)
+
+
 def test_camera_entry_points_and_finalize():
     s = rt.Scene.builtin(6, 40, 40)
     o = ob.OracleScene.builtin(6, 40, 40)
