@@ -105,6 +105,35 @@ def test_image_with_shared_random_numbers_matches_golden(sid):
     assert close.mean() >= 0.99, close.mean()
 
 
+@pytest.mark.parametrize("sid", [2, 4, 5, 101])
+def test_scenes_without_fixtures_against_the_oracle_directly(sid):
+    """The reference's scenes that have no committed fixture (two checker spheres, the earth, the five quads) and
+    the glass-sphere Cornell variant: camera rays, their hits, one scattered generation of rays and a small image
+    with shared random numbers, GPU against the oracle run in this process."""
+    w, h, spp = 40, 30, 3
+    scene = rt.Scene.builtin(sid, w, h)
+    oracle = ob.OracleScene.builtin(sid, w, h)
+    pixels = np.arange(w * h, dtype=np.uint32)
+    rays = scene.primary_rays(pixels, sample=2, seed=9)
+    assert rays.tobytes() == oracle.primary_rays(pixels, sample=2, seed=9).tobytes()
+    gpu, cpu = scene.intersect(rays, seed=9), oracle.intersect(rays, seed=9)
+    assert check_hits(gpu, cpu) == 1.0
+    keep = cpu["hit"] == 1
+    sc_g, att_g, em_g = scene.shade(rays[keep], cpu[keep], seed=9)
+    sc_c, att_c, em_c = oracle.shade(rays[keep], cpu[keep], seed=9)
+    assert np.array_equal(sc_g["tmin"], sc_c["tmin"])
+    assert np.abs(sc_g["direction"] - sc_c["direction"]).max(initial=0.0) <= 1e-5
+    assert np.abs(att_g - att_c).max(initial=0.0) <= 1e-5 and np.abs(em_g - em_c).max(initial=0.0) <= 1e-5
+    second = sc_c[sc_c["tmin"] > 0]
+    if len(second):
+        assert check_hits(scene.intersect(second, seed=9), oracle.intersect(second, seed=9)) == 1.0
+    scene.set_seed(9)
+    scene.render_samples(spp)
+    want = oracle.render(spp, first_sample=1, seed=9)
+    rmse = np.sqrt(np.mean((enc(scene.accumulator(), spp) - enc(want, spp)) ** 2))
+    assert rmse <= 1e-3, rmse
+
+
 @pytest.mark.parametrize("sid,spp", [(0, 64), (6, 64), (8, 64), (100, 64)])
 def test_image_statistics_match_reference_random_numbers(sid, spp):
     w = h = 48
