@@ -211,10 +211,11 @@ def _random_scene(s, rng):
     return s
 
 
-def test_random_scene_through_the_builder_api():
-    gpu = _random_scene(rt.Scene(), np.random.default_rng(42))
-    cpu = _random_scene(ob.OracleScene(), np.random.default_rng(42))
-    rng = np.random.default_rng(1)
+@pytest.mark.parametrize("scene_seed", [42, 7, 2026])
+def test_random_scene_through_the_builder_api(scene_seed):
+    gpu = _random_scene(rt.Scene(), np.random.default_rng(scene_seed))
+    cpu = _random_scene(ob.OracleScene(), np.random.default_rng(scene_seed))
+    rng = np.random.default_rng(scene_seed + 1)
     n = 20000
     rays = np.zeros(n, _abi.ray_dtype())
     rays["origin"] = rng.uniform(-8, 8, (n, 3))
