@@ -52,7 +52,7 @@ struct EventPair {
 };
 
 constexpr int MAX_PIPES = 2;
-constexpr uint64_t BYTES_PER_PATH = 6 * sizeof(float4) + sizeof(uint2) + sizeof(uint32_t) + sizeof(float4);
+constexpr uint64_t BYTES_PER_PATH = 4 * sizeof(float4) + 2 * 3 * sizeof(float) + sizeof(uint2) + sizeof(uint32_t) + sizeof(float4);
 
 // Everything one batch in flight needs: the ray / throughput queues (double-buffered), hit
 // records, the list of textured hits, per-path radiance, queue counters, and the extend
@@ -62,7 +62,7 @@ struct Pipe {
     uint64_t cap = 0;              // paths the queues hold
     float4* ray_o[2] = {nullptr, nullptr};
     float4* ray_d[2] = {nullptr, nullptr};
-    float4* thr[2] = {nullptr, nullptr};
+    float* thr[2] = {nullptr, nullptr};      // throughput, three floats per slot
     uint2* hits = nullptr;
     uint32_t* tex_list = nullptr;
     float4* radiance = nullptr;
@@ -122,7 +122,8 @@ void free_queues(Pipe& p) {
         if (p.ray_o[i]) (void)hipFree(p.ray_o[i]);
         if (p.ray_d[i]) (void)hipFree(p.ray_d[i]);
         if (p.thr[i]) (void)hipFree(p.thr[i]);
-        p.ray_o[i] = p.ray_d[i] = p.thr[i] = nullptr;
+        p.ray_o[i] = p.ray_d[i] = nullptr;
+        p.thr[i] = nullptr;
     }
     if (p.hits) (void)hipFree(p.hits);
     if (p.tex_list) (void)hipFree(p.tex_list);
@@ -139,7 +140,7 @@ int ensure_queues(rt_ctx* c, Pipe& p, uint64_t paths, uint32_t n_counts) {
         for (int i = 0; i < 2; ++i) {
             HIP_TRY(hipMalloc((void**)&p.ray_o[i], paths * sizeof(float4)));
             HIP_TRY(hipMalloc((void**)&p.ray_d[i], paths * sizeof(float4)));
-            HIP_TRY(hipMalloc((void**)&p.thr[i], paths * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&p.thr[i], paths * 3 * sizeof(float)));
         }
         HIP_TRY(hipMalloc((void**)&p.hits, paths * sizeof(uint2)));
         HIP_TRY(hipMalloc((void**)&p.tex_list, paths * sizeof(uint32_t)));

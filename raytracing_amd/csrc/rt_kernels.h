@@ -20,7 +20,7 @@ struct BatchInfo {
 // kept out of the tree (scenes with sc.n_global != 0); the extend kernel starts from that record.  With
 // NULL the caller runs launch_first_leaves before the first launch_extend, as it does before all later ones.
 void launch_raygen(hipStream_t st, uint32_t max_blocks, const DScene& sc, const DCamera& cam, const BatchInfo& b, uint64_t seed, float4* ray_o,
-                   float4* ray_d, float4* thr, uint2* first_hits, uint32_t* counts, uint32_t n_counts);
+                   float4* ray_d, float* thr, uint2* first_hits, uint32_t* counts, uint32_t n_counts);
 void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam, uint64_t seed, uint32_t sample, const uint32_t* pixels,
                          unsigned long long n, rt_ray* out);
 // Lane-count thresholds of the extend kernel's loop (see k_extend).
@@ -42,7 +42,7 @@ void launch_extend(hipStream_t st, uint32_t resident_blocks, uint32_t upper_boun
 // textured materials (filled by the first kernel, consumed by the second).
 void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const DCamera& cam, const BatchInfo& b,
                   uint64_t seed, uint32_t bounce, uint32_t* counts, uint32_t* tex_count, uint32_t* tex_list, const float4* ray_o,
-                  const float4* ray_d, const float4* thr, const uint2* hits, float4* out_o, float4* out_d, float4* out_thr, float4* radiance,
+                  const float4* ray_d, const float* thr, const uint2* hits, float4* out_o, float4* out_d, float* out_thr, float4* radiance,
                   bool scene_has_textures);
 void launch_accumulate(hipStream_t st, uint32_t max_blocks, const BatchInfo& b, const float4* radiance, float4* acc);
 void launch_finalize(hipStream_t st, uint32_t max_blocks, const float4* acc, unsigned long long n_pixels, float inv_samples, int mode,

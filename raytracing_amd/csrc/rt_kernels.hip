@@ -806,6 +806,16 @@ RT_D void flush_probe(DCounters* c, const Probe& pr, uint32_t segments, uint32_t
 // kernels
 // ---------------------------------------------------------------------------
 
+// The throughput queue holds three floats per slot (12-byte stride).
+RT_D float4 load_thr(const float* base, uint32_t i) {
+    const float* p = base + 3 * (size_t)i;
+    return make_float4(p[0], p[1], p[2], 0.0f);
+}
+RT_D void store_thr(float* base, uint32_t i, float4 v) {
+    float* p = base + 3 * (size_t)i;
+    p[0] = v.x; p[1] = v.y; p[2] = v.z;
+}
+
 // get_ray + pixel_sample_square + defocus_disk_sample (src/camera.rs:311-320,368-380).
 // Draw order on the camera stream: jitter x, jitter y, [disk trials], time.
 RT_D void primary_ray(const DCamera& cam, uint64_t seed, uint32_t pixel, uint32_t sample, float3& origin, float3& dir, float& time) {
@@ -832,7 +842,7 @@ RT_D void primary_ray(const DCamera& cam, uint64_t seed, uint32_t pixel, uint32_
 // One thread per path of the batch.  Path index = s_local * n_pixels + pixel_local,
 // which is also the initial queue slot.
 __global__ __launch_bounds__(256) void k_raygen(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, float4* __restrict__ ray_o,
-                                                float4* __restrict__ ray_d, float4* __restrict__ thr, uint2* __restrict__ first_hits,
+                                                float4* __restrict__ ray_d, float* __restrict__ thr, uint2* __restrict__ first_hits,
                                                 uint32_t* __restrict__ counts, uint32_t n_counts) {
     const uint32_t total = b.n_pixels * b.n_samples;
     if (blockIdx.x == 0) {
@@ -847,7 +857,7 @@ __global__ __launch_bounds__(256) void k_raygen(DScene sc, DCamera cam, BatchInf
         const float4 ro = make_float4(origin.x, origin.y, origin.z, time), rd = make_float4(dir.x, dir.y, dir.z, __uint_as_float(i));
         ray_o[i] = ro;
         ray_d[i] = rd;
-        thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        store_thr(thr, i, make_float4(1.0f, 1.0f, 1.0f, 0.0f));
         if (first_hits) first_hits[i] = first_leaves_hit(sc, b, seed, 0, ro, rd);
     }
 }
@@ -1137,9 +1147,9 @@ static constexpr int SHADE_TILE = SHADE_BLOCK * SHADE_PER_THREAD;
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                        uint32_t* __restrict__ counts, uint32_t* __restrict__ tex_count,
                                                        uint32_t* __restrict__ tex_list, const float4* __restrict__ ray_o,
-                                                       const float4* __restrict__ ray_d, const float4* __restrict__ thr,
+                                                       const float4* __restrict__ ray_d, const float* __restrict__ thr,
                                                        const uint2* __restrict__ hits, float4* __restrict__ out_o,
-                                                       float4* __restrict__ out_d, float4* __restrict__ out_thr,
+                                                       float4* __restrict__ out_d, float* __restrict__ out_thr,
                                                        float4* __restrict__ radiance) {
     __shared__ float4 s_out[3][SHADE_TILE];
     __shared__ uint16_t s_order[SHADE_TILE];
@@ -1198,7 +1208,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
             if (e < tile_n) {
                 const uint32_t i = tile + s_order[e];
                 if (e >= first_textured) tex_list[s_tex_base + (e - first_textured)] = i;
-                else alive = shade_one<false>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], thr[i], hits[i], radiance, no, nd, nt);
+                else alive = shade_one<false>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], load_thr(thr, i), hits[i], radiance, no, nd, nt);
             }
             unsigned long long mask = __ballot(alive);
             if (mask) {
@@ -1221,7 +1231,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
         for (uint32_t j = tid; j < n_alive; j += SHADE_BLOCK) {
             out_o[base + j] = s_out[0][j];
             out_d[base + j] = s_out[1][j];
-            out_thr[base + j] = s_out[2][j];
+            store_thr(out_thr, base + j, s_out[2][j]);
         }
         __syncthreads();
     }
@@ -1231,9 +1241,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_unsorted(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ tex_count,
                                                                 uint32_t* __restrict__ tex_list, const float4* __restrict__ ray_o,
-                                                                const float4* __restrict__ ray_d, const float4* __restrict__ thr,
+                                                                const float4* __restrict__ ray_d, const float* __restrict__ thr,
                                                                 const uint2* __restrict__ hits, float4* __restrict__ out_o,
-                                                                float4* __restrict__ out_d, float4* __restrict__ out_thr,
+                                                                float4* __restrict__ out_d, float* __restrict__ out_thr,
                                                                 float4* __restrict__ radiance) {
     __shared__ float4 s_out[3][SHADE_TILE];
     __shared__ uint32_t s_tex[SHADE_TILE];
@@ -1251,7 +1261,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_unsorted(DScene sc, DCame
             if (i < n) {
                 uint2 h = hits[i];
                 textured = h.y != REF_NONE && (leaf_meta(sc, h.y)->w & 0xFFu) == CLS_TEXTURED;
-                if (!textured) alive = shade_one<false>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], thr[i], h, radiance, no, nd, nt);
+                if (!textured) alive = shade_one<false>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], load_thr(thr, i), h, radiance, no, nd, nt);
             }
             unsigned long long mask = __ballot(alive), tmask = __ballot(textured);
             if (mask) {
@@ -1281,7 +1291,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_unsorted(DScene sc, DCame
         for (uint32_t j = tid; j < n_alive; j += SHADE_BLOCK) {
             out_o[base + j] = s_out[0][j];
             out_d[base + j] = s_out[1][j];
-            out_thr[base + j] = s_out[2][j];
+            store_thr(out_thr, base + j, s_out[2][j]);
         }
         for (uint32_t j = tid; j < n_tex; j += SHADE_BLOCK) tex_list[tbase + j] = s_tex[j];
         __syncthreads();
@@ -1293,9 +1303,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_unsorted(DScene sc, DCame
 __global__ __launch_bounds__(256) void k_shade_textured(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                         uint32_t* __restrict__ counts, const uint32_t* __restrict__ tex_count,
                                                         const uint32_t* __restrict__ tex_list, const float4* __restrict__ ray_o,
-                                                        const float4* __restrict__ ray_d, const float4* __restrict__ thr,
+                                                        const float4* __restrict__ ray_d, const float* __restrict__ thr,
                                                         const uint2* __restrict__ hits, float4* __restrict__ out_o,
-                                                        float4* __restrict__ out_d, float4* __restrict__ out_thr,
+                                                        float4* __restrict__ out_d, float* __restrict__ out_thr,
                                                         float4* __restrict__ radiance) {
     __shared__ uint32_t s_wave_count[4], s_base;
     const uint32_t n = *tex_count;
@@ -1306,7 +1316,7 @@ __global__ __launch_bounds__(256) void k_shade_textured(DScene sc, DCamera cam, 
         float4 no, nd, nt;
         if (j < n) {
             const uint32_t i = tex_list[j];
-            alive = shade_one<true>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], thr[i], hits[i], radiance, no, nd, nt);
+            alive = shade_one<true>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], load_thr(thr, i), hits[i], radiance, no, nd, nt);
         }
         unsigned long long mask = __ballot(alive);
         if (lane == 0) s_wave_count[wave] = (uint32_t)__popcll(mask);
@@ -1321,7 +1331,7 @@ __global__ __launch_bounds__(256) void k_shade_textured(DScene sc, DCamera cam, 
             for (uint32_t w2 = 0; w2 < wave; ++w2) slot += s_wave_count[w2];
             out_o[slot] = no;
             out_d[slot] = nd;
-            out_thr[slot] = nt;
+            store_thr(out_thr, slot, nt);
         }
         __syncthreads();
     }
@@ -1441,7 +1451,7 @@ static inline uint32_t grid_for(unsigned long long n, uint32_t max_blocks) {
 }
 
 void launch_raygen(hipStream_t st, uint32_t max_blocks, const DScene& sc, const DCamera& cam, const BatchInfo& b, uint64_t seed, float4* ray_o,
-                   float4* ray_d, float4* thr, uint2* first_hits, uint32_t* counts, uint32_t n_counts) {
+                   float4* ray_d, float* thr, uint2* first_hits, uint32_t* counts, uint32_t n_counts) {
     uint32_t total = b.n_pixels * b.n_samples;
     hipLaunchKernelGGL(k_raygen, dim3(grid_for(total, max_blocks)), dim3(256), 0, st, sc, cam, b, seed, ray_o, ray_d, thr,
                        sc.n_global != 0 ? first_hits : nullptr, counts, n_counts);
@@ -1492,7 +1502,7 @@ void launch_extend(hipStream_t st, uint32_t resident_blocks, uint32_t upper_boun
 
 void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const DCamera& cam, const BatchInfo& b,
                   uint64_t seed, uint32_t bounce, uint32_t* counts, uint32_t* tex_count, uint32_t* tex_list, const float4* ray_o,
-                  const float4* ray_d, const float4* thr, const uint2* hits, float4* out_o, float4* out_d, float4* out_thr, float4* radiance,
+                  const float4* ray_d, const float* thr, const uint2* hits, float4* out_o, float4* out_d, float* out_thr, float4* radiance,
                   bool scene_has_textures) {
     unsigned long long tiles = ((unsigned long long)upper_bound + SHADE_TILE - 1) / SHADE_TILE;
     uint32_t grid = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(tiles, 1), max_blocks);
