@@ -43,7 +43,7 @@ int fail(int code, const char* fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                                \
     } while (0)
 
-constexpr uint64_t DEFAULT_BATCH_PATHS = 128ull << 20;  // 124 B of queue memory per path
+constexpr uint64_t DEFAULT_BATCH_PATHS = 128ull << 20;  // 116 B of queue memory per path
 constexpr int N_PHASES = 5;
 
 struct EventPair {
