@@ -107,6 +107,7 @@ struct rt_scene {
     DScene d{};
     uint32_t bvh_depth = 0;
     bool has_textures = false;  // some material's texture is not a plain colour
+    bool media_are_single_spheres = true;  // every medium's boundary is one unplaced sphere (the short medium test)
     rt_scene_info info{};
 };
 
@@ -692,8 +693,11 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         }
     };
     for (uint32_t i = 0; i < desc->n_boundary; ++i) boundary_refs[i] = make_leaf(desc->boundary[i].kind, desc->boundary[i].index, placed(desc->boundary[i]));
+    bool media_are_single_spheres = true;
     for (uint32_t i = 0; i < desc->n_media; ++i) {
         const rt_medium& m = desc->media[i];
+        if (m.n_boundary != 1 || desc->boundary[m.first_boundary].kind != RT_PRIM_SPHERE || placed(desc->boundary[m.first_boundary]))
+            media_are_single_spheres = false;
         media[i] = DMedium{m.first_boundary, m.n_boundary, m.neg_inv_density, m.phase_material, m.prim_id, {0, 0, 0}};
         fill_meta(&medium_meta[2 * (size_t)i], m.phase_material, m.prim_id, RT_NO_TRANSFORM);
         for (uint32_t k = 0; k < m.n_boundary; ++k) medium_box[i].grow(box_of(desc->boundary[m.first_boundary + k]));
@@ -770,6 +774,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     rt_scene* sc = new rt_scene();
     sc->ctx = ctx;
     sc->bvh_depth = bvh.max_depth;
+    sc->media_are_single_spheres = media_are_single_spheres;
     auto bail = [&](int code) { rt_scene_destroy(sc); return code; };
 
     std::vector<float4> nodes(bvh.nodes.size() / 4);
@@ -1004,6 +1009,8 @@ int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, ui
         if ((e = ensure_queues(c, c->pipes[i], (uint64_t)chunk_pixels * spb, n_counts))) return e;
     DCamera dcam = to_dcamera(cam);
     DCounters* counters = c->counters_on ? c->d_counters : nullptr;
+    rt::ExtendTuning tune = c->tune;
+    if (tune.medium_min <= 0) tune.medium_min = sc->media_are_single_spheres ? 4 : 24;
 
     HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
     if (n_pipes > 1)
@@ -1037,7 +1044,7 @@ int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, ui
                     }
                     if ((e = phase_begin(c, st, 1, &ep))) return e;
                     launch_extend(st, counters ? c->extend_blocks_counting : c->extend_blocks, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur],
-                                  q.ray_d[cur], q.hits, q.stack_overflow, c->tune, counters);
+                                  q.ray_d[cur], q.hits, q.stack_overflow, tune, counters);
                     if ((e = phase_end(st, ep))) return e;
                     if ((e = phase_begin(c, st, 2, &ep))) return e;
                     launch_shade(st, c->max_blocks, total, sc->d, dcam, b, seed, bounce, q.counts, q.counts + n_queue_counts + bounce, q.tex_list,

@@ -27,7 +27,9 @@ void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam
 struct ExtendTuning {
     int inner_min = 20;   // keep stepping through inner nodes while this many lanes are at one
     int refill_min = 16;  // fetch new rays once this many lanes are free
-    int medium_min = 12;  // run the medium test once this many lanes wait at a medium
+    int medium_min = 0;   // run the medium test once this many lanes wait at a medium; 0: chosen per scene (4 when every
+                          // medium in the tree is bounded by one sphere - a short test -, 24 when some boundary is a list
+                          // of leaves, whose test runs to several hundred instructions)
 };
 int extend_blocks_per_cu(bool counting);
 size_t extend_overflow_bytes(uint32_t blocks);
