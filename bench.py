@@ -110,6 +110,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    reduce_accumulators(acc)           # untimed: the first collective of this size sets up the communicator's channels
     torch.cuda.synchronize()
     acc.zero_()
     scene.set_phase_timing(True)
