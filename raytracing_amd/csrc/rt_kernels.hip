@@ -102,23 +102,25 @@ RT_D void hit_to_world(const DScene& sc, uint32_t xf, float3& p, float3& n) {
 template <bool COUNT>
 RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float time, float a, float tmin, float tmax, float& t, Probe& pr) {
     const uint32_t kind = ref_kind(ref), idx = ref_index(ref);
-    if (kind == KIND_SPHERE) {
+    if (kind != KIND_QUAD) {  // a sphere, still or moving: the two kinds share one copy of the root computation
         if (COUNT) pr.spheres++;
-        float4 s = sc.spheres[idx];
+        float4 s;
+        float3 c;
+        const float4* xf;
+        if (kind == KIND_SPHERE) {
+            s = sc.spheres[idx];
+            c = f3(s);
+            xf = sc.sphere_xf + 2 * (size_t)idx;
+        } else {
+            s = sc.moving[2 * (size_t)idx];
+            c = f3(s) + time * f3(sc.moving[2 * (size_t)idx + 1]);  // MovingSphere::hit, src/hittable.rs:310
+            xf = sc.moving_xf + 2 * (size_t)idx;
+        }
         if (ref_placed(ref)) {
-            ray_to_object(sc.sphere_xf[2 * (size_t)idx], sc.sphere_xf[2 * (size_t)idx + 1], o, d);
+            ray_to_object(xf[0], xf[1], o, d);
             a = dot3(d, d);
         }
-        return sphere_root(f3(s), s.w, o, d, a, tmin, tmax, t);
-    } else if (kind == KIND_MOVING) {
-        if (COUNT) pr.spheres++;
-        float4 s0 = sc.moving[2 * (size_t)idx], s1 = sc.moving[2 * (size_t)idx + 1];
-        if (ref_placed(ref)) {
-            ray_to_object(sc.moving_xf[2 * (size_t)idx], sc.moving_xf[2 * (size_t)idx + 1], o, d);
-            a = dot3(d, d);
-        }
-        float3 c = f3(s0) + time * f3(s1);  // MovingSphere::hit, src/hittable.rs:310
-        return sphere_root(c, s0.w, o, d, a, tmin, tmax, t);
+        return sphere_root(c, s.w, o, d, a, tmin, tmax, t);
     } else {
         if (COUNT) pr.quads++;
         const float4* q4 = sc.quads + 4 * (size_t)idx;
