@@ -355,6 +355,7 @@ int validate(const rt_scene_desc* d) {
     for (uint32_t i = 0; i < d->n_perlins; ++i) {
         const rt_perlin& p = d->perlins[i];
         if (p.point_count == 0 || !p.rand_vecs || !p.perm_x || !p.perm_y || !p.perm_z) return fail(RT_ERR_INVALID_ARGUMENT, "perlins[%u]: empty tables", i);
+        if (p.point_count > (1u << 20)) return fail(RT_ERR_UNSUPPORTED, "perlins[%u]: %u points (at most %u are supported)", i, p.point_count, 1u << 20);
         for (uint32_t k = 0; k < p.point_count; ++k)
             if (p.perm_x[k] >= p.point_count || p.perm_y[k] >= p.point_count || p.perm_z[k] >= p.point_count)
                 return fail(RT_ERR_INVALID_ARGUMENT, "perlins[%u]: permutation entry out of range", i);
@@ -838,13 +839,20 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     std::vector<DPerlin> perlins(desc->n_perlins);
     for (uint32_t i = 0; i < desc->n_perlins; ++i) {
         const rt_perlin& p = desc->perlins[i];
-        std::vector<float4> vecs(p.point_count);
-        std::vector<uint32_t> perm(3 * (size_t)p.point_count);
-        for (uint32_t k = 0; k < p.point_count; ++k) {
-            vecs[k] = make_float4(p.rand_vecs[3 * k], p.rand_vecs[3 * k + 1], p.rand_vecs[3 * k + 2], 0.0f);
-            perm[k] = p.perm_x[k];
-            perm[p.point_count + k] = p.perm_y[k];
-            perm[2 * (size_t)p.point_count + k] = p.perm_z[k];
+        // tables expanded so that the kernels index them without the reference's `% point_count` (layout: DPerlin)
+        size_t pow2 = 1;
+        while (pow2 < p.point_count) pow2 <<= 1;
+        std::vector<float4> vecs(pow2);
+        std::vector<uint32_t> perm(3 * 256);
+        for (size_t v = 0; v < pow2; ++v) {
+            const size_t k = v % p.point_count;
+            vecs[v] = make_float4(p.rand_vecs[3 * k], p.rand_vecs[3 * k + 1], p.rand_vecs[3 * k + 2], 0.0f);
+        }
+        for (uint32_t v = 0; v < 256; ++v) {
+            const uint32_t k = v % p.point_count;
+            perm[v] = p.perm_x[k];
+            perm[256 + v] = p.perm_y[k];
+            perm[512 + v] = p.perm_z[k];
         }
         if ((e = upload(sc, vecs, &perlins[i].vecs))) return bail(e);
         if ((e = upload(sc, perm, &perlins[i].perm))) return bail(e);

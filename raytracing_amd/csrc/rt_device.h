@@ -88,9 +88,12 @@ struct DImage {
     uint32_t _pad;
 };
 
+// PerlinNoise's tables (src/perlin_noise.rs:17-37), laid out so that a lookup needs no remainder operation:
+// the reference indexes perm_x[(i & 255) % n] and rand_vecs[(px ^ py ^ pz) % n] with n = point_count.
 struct DPerlin {
-    const float4* vecs;      // point_count unit vectors (xyz, 0)
-    const uint32_t* perm;    // 3 * point_count: x | y | z
+    const float4* vecs;      // vecs[v] = rand_vecs[v % n] (xyz, 0) for v below the power of two >= n: the xor of three
+                             // permutation entries (each < n) stays below that power of two
+    const uint32_t* perm;    // 3 * 256: perm[256 a + v] = perm_a[v % n] for axis a = x, y, z and v = 0..255
     uint32_t point_count;
     uint32_t _pad;
 };

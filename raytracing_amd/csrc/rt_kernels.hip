@@ -578,13 +578,13 @@ RT_D float perlin_noise(const DPerlin& pn, float3 p) {
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     float u = p.x - fx, v = p.y - fy, w = p.z - fz;
     int i = (int)fx, j = (int)fy, k = (int)fz;
-    const uint32_t n = pn.point_count;
+    // the tables are expanded at scene creation (DPerlin), which takes the `% point_count` out of every lookup
     const uint32_t* px = pn.perm;
-    const uint32_t* py = pn.perm + n;
-    const uint32_t* pz = pn.perm + 2 * n;
-    uint32_t ix[2] = {px[(uint32_t)(i & 255) % n], px[(uint32_t)((i + 1) & 255) % n]};
-    uint32_t iy[2] = {py[(uint32_t)(j & 255) % n], py[(uint32_t)((j + 1) & 255) % n]};
-    uint32_t iz[2] = {pz[(uint32_t)(k & 255) % n], pz[(uint32_t)((k + 1) & 255) % n]};
+    const uint32_t* py = pn.perm + 256;
+    const uint32_t* pz = pn.perm + 512;
+    uint32_t ix[2] = {px[i & 255], px[(i + 1) & 255]};
+    uint32_t iy[2] = {py[j & 255], py[(j + 1) & 255]};
+    uint32_t iz[2] = {pz[k & 255], pz[(k + 1) & 255]};
     float uu = u * u * (3.0f - 2.0f * u);
     float vv = v * v * (3.0f - 2.0f * v);
     float ww = w * w * (3.0f - 2.0f * w);
@@ -595,7 +595,7 @@ RT_D float perlin_noise(const DPerlin& pn, float3 p) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                float4 g = pn.vecs[(ix[a] ^ iy[b] ^ iz[c]) % n];
+                float4 g = pn.vecs[ix[a] ^ iy[b] ^ iz[c]];
                 float3 wv = f3(u - (float)a, v - (float)b, w - (float)c);
                 accum += (a ? uu : 1.0f - uu) * (b ? vv : 1.0f - vv) * (c ? ww : 1.0f - ww) * dot3(f3(g), wv);
             }
