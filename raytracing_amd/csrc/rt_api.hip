@@ -857,8 +857,9 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         if ((e = upload(sc, vecs, &perlins[i].vecs))) return bail(e);
         if ((e = upload(sc, perm, &perlins[i].perm))) return bail(e);
         perlins[i].point_count = p.point_count;
-        perlins[i]._pad = 0;
+        perlins[i].n_vecs = (uint32_t)pow2;
     }
+    sc->d.lds_perlin = (desc->n_perlins == 1 && perlins[0].n_vecs <= LDS_PERLIN_VECS) ? 1u : 0u;
     if ((e = upload(sc, perlins, &sc->d.perlins))) return bail(e);
 
     sc->d.root = bvh.root;

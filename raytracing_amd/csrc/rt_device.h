@@ -95,8 +95,9 @@ struct DPerlin {
                              // permutation entries (each < n) stays below that power of two
     const uint32_t* perm;    // 3 * 256: perm[256 a + v] = perm_a[v % n] for axis a = x, y, z and v = 0..255
     uint32_t point_count;
-    uint32_t _pad;
+    uint32_t n_vecs;         // entries of vecs: the power of two >= point_count
 };
+static constexpr uint32_t LDS_PERLIN_VECS = 256;  // largest n_vecs the LDS copy holds (the reference's tables have 64 - 256 points)
 
 struct DScene {
     const float4* nodes;
@@ -124,6 +125,7 @@ struct DScene {
     uint32_t n_media;
     uint32_t n_materials;
     uint32_t n_global;         // leaves kept out of the tree: tested first for every ray
+    uint32_t lds_perlin;       // 1: the scene has exactly one noise table and it fits the textured-shade kernel's LDS copy
     const uint32_t* global_refs;  // n_global leaf references tested ahead of the tree
 };
 

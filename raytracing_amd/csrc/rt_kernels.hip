@@ -574,17 +574,32 @@ RT_D void ensure_uv(HitGeom& g) {
 // ---------------------------------------------------------------------------
 // PerlinNoise::noise / turbulance (src/perlin_noise.rs:39-102)
 // ---------------------------------------------------------------------------
-RT_D float perlin_noise(const DPerlin& pn, float3 p) {
+// Where the tables are read from: global memory, or the copy a block of the textured-shade kernel keeps in LDS
+// (every lookup is a gather by 64 different indices; the LDS serves those several times faster than the L1 path).
+typedef __attribute__((address_space(3))) const float4v lds_const_float4v;
+typedef __attribute__((address_space(3))) const uint32_t lds_const_u32;
+struct PerlinGlobal {
+    const float4* vecs;
+    const uint32_t* perm;
+    RT_D float4 vec(uint32_t i) const { return vecs[i]; }
+    RT_D uint32_t permuted(uint32_t i) const { return perm[i]; }
+};
+struct PerlinLds {
+    lds_const_float4v* vecs;
+    lds_const_u32* perm;
+    bool filled;  // false: no LDS copy, read the tables from global memory
+    RT_D float4 vec(uint32_t i) const { return f4(vecs[i]); }
+    RT_D uint32_t permuted(uint32_t i) const { return perm[i]; }
+};
+template <class Tables>
+RT_D float perlin_noise(const Tables& pn, float3 p) {
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     float u = p.x - fx, v = p.y - fy, w = p.z - fz;
     int i = (int)fx, j = (int)fy, k = (int)fz;
     // the tables are expanded at scene creation (DPerlin), which takes the `% point_count` out of every lookup
-    const uint32_t* px = pn.perm;
-    const uint32_t* py = pn.perm + 256;
-    const uint32_t* pz = pn.perm + 512;
-    uint32_t ix[2] = {px[i & 255], px[(i + 1) & 255]};
-    uint32_t iy[2] = {py[j & 255], py[(j + 1) & 255]};
-    uint32_t iz[2] = {pz[k & 255], pz[(k + 1) & 255]};
+    uint32_t ix[2] = {pn.permuted(i & 255), pn.permuted((i + 1) & 255)};
+    uint32_t iy[2] = {pn.permuted(256 + (j & 255)), pn.permuted(256 + ((j + 1) & 255))};
+    uint32_t iz[2] = {pn.permuted(512 + (k & 255)), pn.permuted(512 + ((k + 1) & 255))};
     float uu = u * u * (3.0f - 2.0f * u);
     float vv = v * v * (3.0f - 2.0f * v);
     float ww = w * w * (3.0f - 2.0f * w);
@@ -595,15 +610,17 @@ RT_D float perlin_noise(const DPerlin& pn, float3 p) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                float4 g = pn.vecs[ix[a] ^ iy[b] ^ iz[c]];
+                float4 g = pn.vec(ix[a] ^ iy[b] ^ iz[c]);
                 float3 wv = f3(u - (float)a, v - (float)b, w - (float)c);
                 accum += (a ? uu : 1.0f - uu) * (b ? vv : 1.0f - vv) * (c ? ww : 1.0f - ww) * dot3(f3(g), wv);
             }
     return accum;
 }
 
-RT_D float perlin_turbulance(const DPerlin& pn, float3 p, int depth) {
+template <class Tables>
+RT_D float perlin_turbulance(const Tables& pn, float3 p, int depth) {
     float accum = 0.0f, weight = 1.0f;
+#pragma unroll 1
     for (int i = 0; i < depth; ++i) {
         accum += weight * perlin_noise(pn, p);
         weight *= 0.5f;
@@ -651,7 +668,7 @@ RT_D ShadeRec shade_rec_of_leaf(const DScene& sc, uint4 m0, uint4 m1) {
 }
 
 // Texture::value (src/texture.rs:40-73) for textures that are not a plain colour
-RT_D float3 texture_value_slow(const DScene& sc, uint32_t tex_id, HitGeom& g) {
+RT_D float3 texture_value_slow(const DScene& sc, uint32_t tex_id, HitGeom& g, PerlinLds lds_perlin) {
     DTexture t = sc.textures[tex_id];
     for (int guard = 0; guard < 16 && t.kind == RT_TEX_CHECKER; ++guard) {
         float sum = floorf(t.scale * g.p.x) + floorf(t.scale * g.p.y) + floorf(t.scale * g.p.z);
@@ -677,16 +694,23 @@ RT_D float3 texture_value_slow(const DScene& sc, uint32_t tex_id, HitGeom& g) {
         return px * px;
     }
     if (t.kind == RT_TEX_NOISE) {
-        float s = 1.0f + sinf(t.scale * g.p.z + 10.0f * perlin_turbulance(sc.perlins[t.perlin], g.p, 7));
+        float turb;
+        if (lds_perlin.filled) {  // the scene's one table, copied to LDS by the caller
+            turb = perlin_turbulance(lds_perlin, g.p, 7);
+        } else {
+            const DPerlin pn = sc.perlins[t.perlin];
+            turb = perlin_turbulance(PerlinGlobal{pn.vecs, pn.perm}, g.p, 7);
+        }
+        float s = 1.0f + sinf(t.scale * g.p.z + 10.0f * turb);
         return f3(s * 0.5f, s * 0.5f, s * 0.5f);
     }
     return f3(0, 0, 0);
 }
 
 template <bool TEXTURES>
-RT_D float3 texture_value(const DScene& sc, const ShadeRec& rec, HitGeom& g) {
+RT_D float3 texture_value(const DScene& sc, const ShadeRec& rec, HitGeom& g, PerlinLds lds_perlin) {
     if (!TEXTURES || rec.tex_kind == RT_TEX_SOLID) return rec.colour;
-    return texture_value_slow(sc, rec.tex_id, g);
+    return texture_value_slow(sc, rec.tex_id, g, lds_perlin);
 }
 
 // Vec3::random_unit (src/math/vec3.rs:57-67)
@@ -717,13 +741,13 @@ struct ScatterResult {
 // Material::emitted + Material::scatter (src/material.rs:65-122).  Every kind evaluates its
 // texture exactly once (attenuation, or the emitted colour of a light), so that is done first.
 template <bool TEXTURES>
-RT_D ScatterResult shade_hit(const DScene& sc, const ShadeRec& m, HitGeom& g, float3 d_in, Rng& rng) {
+RT_D ScatterResult shade_hit(const DScene& sc, const ShadeRec& m, HitGeom& g, float3 d_in, Rng& rng, PerlinLds lds_perlin = PerlinLds{nullptr, nullptr, false}) {
     ScatterResult r;
     r.emitted = f3(0, 0, 0);
     r.attenuation = f3(0, 0, 0);
     r.dir = f3(0, 0, 0);
     r.scattered = false;
-    float3 tex = texture_value<TEXTURES>(sc, m, g);
+    float3 tex = texture_value<TEXTURES>(sc, m, g, lds_perlin);
     switch (m.kind) {
         case RT_MAT_LAMBERTIAN: {
             float3 dir = g.normal + random_unit(rng);
@@ -1088,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_first_leaves(DScene sc, BatchInfo b, ui
 // radiance when the path ends here, otherwise returns the next ray.
 template <bool TEXTURES>
 RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, uint64_t seed, uint32_t bounce, float4 ro, float4 rd, float4 th,
-                    uint2 h, float4* __restrict__ radiance, float4& no, float4& nd, float4& nt) {
+                    uint2 h, float4* __restrict__ radiance, float4& no, float4& nd, float4& nt, PerlinLds lds_perlin = PerlinLds{nullptr, nullptr, false}) {
     uint32_t path = __float_as_uint(rd.w);
     float3 T = f3(th);
     if (h.y == REF_NONE) {  // src/camera.rs:347-349
@@ -1104,7 +1128,7 @@ RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, ui
     uint32_t s_local = path / b.n_pixels;
     Rng rng;
     rng.init(path_key(seed, b.first_pixel + (path - s_local * b.n_pixels), b.first_sample + s_local), bounce, STREAM_SCATTER);
-    ScatterResult r = shade_hit<TEXTURES>(sc, rec, g, d, rng);
+    ScatterResult r = shade_hit<TEXTURES>(sc, rec, g, d, rng, lds_perlin);
     if (!r.scattered) {  // src/camera.rs:354-355
         float3 c = T * r.emitted;
         radiance[path] = make_float4(c.x, c.y, c.z, 0.0f);
@@ -1302,7 +1326,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_unsorted(DScene sc, DCame
 
 // The hits k_shade set aside: materials with checker, image or perlin-noise textures.  One global
 // atomic per block appends the block's survivors.
-__global__ __launch_bounds__(256) void k_shade_textured(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade_textured(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                         uint32_t* __restrict__ counts, const uint32_t* __restrict__ tex_count,
                                                         const uint32_t* __restrict__ tex_list, const float4* __restrict__ ray_o,
                                                         const float4* __restrict__ ray_d, const float* __restrict__ thr,
@@ -1310,7 +1334,21 @@ __global__ __launch_bounds__(256) void k_shade_textured(DScene sc, DCamera cam, 
                                                         float4* __restrict__ out_d, float* __restrict__ out_thr,
                                                         float4* __restrict__ radiance) {
     __shared__ uint32_t s_wave_count[4], s_base;
+    __shared__ float4v s_vecs[LDS_PERLIN_VECS];
+    __shared__ uint32_t s_perm[3 * 256];
     const uint32_t n = *tex_count;
+    if (blockIdx.x * blockDim.x >= n) return;  // no work for this block (the whole block leaves)
+    PerlinLds lds_perlin{(lds_const_float4v*)s_vecs, (lds_const_u32*)s_perm, false};
+    if (sc.lds_perlin) {
+        const DPerlin pn = sc.perlins[0];
+        for (uint32_t i = threadIdx.x; i < pn.n_vecs; i += blockDim.x) {
+            const float4 v = pn.vecs[i];
+            s_vecs[i] = float4v{v.x, v.y, v.z, v.w};
+        }
+        for (uint32_t i = threadIdx.x; i < 3 * 256; i += blockDim.x) s_perm[i] = pn.perm[i];
+        __syncthreads();
+        lds_perlin.filled = true;
+    }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t first = blockIdx.x * blockDim.x; first < n; first += gridDim.x * blockDim.x) {
         const uint32_t j = first + threadIdx.x;
@@ -1318,7 +1356,7 @@ __global__ __launch_bounds__(256) void k_shade_textured(DScene sc, DCamera cam, 
         float4 no, nd, nt;
         if (j < n) {
             const uint32_t i = tex_list[j];
-            alive = shade_one<true>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], load_thr(thr, i), hits[i], radiance, no, nd, nt);
+            alive = shade_one<true>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], load_thr(thr, i), hits[i], radiance, no, nd, nt, lds_perlin);
         }
         unsigned long long mask = __ballot(alive);
         if (lane == 0) s_wave_count[wave] = (uint32_t)__popcll(mask);
