@@ -578,11 +578,15 @@ RT_D void ensure_uv(HitGeom& g) {
 // (every lookup is a gather by 64 different indices; the LDS serves those several times faster than the L1 path).
 typedef __attribute__((address_space(3))) const float4v lds_const_float4v;
 typedef __attribute__((address_space(3))) const uint32_t lds_const_u32;
+// (pointers that were themselves read from memory say "global" explicitly: the compiler cannot know, and would
+// fall back to the slower flat loads)
+typedef __attribute__((address_space(1))) const float4v global_const_float4v;
+typedef __attribute__((address_space(1))) const uint32_t global_const_u32;
 struct PerlinGlobal {
     const float4* vecs;
     const uint32_t* perm;
-    RT_D float4 vec(uint32_t i) const { return vecs[i]; }
-    RT_D uint32_t permuted(uint32_t i) const { return perm[i]; }
+    RT_D float4 vec(uint32_t i) const { return f4(((global_const_float4v*)vecs)[i]); }
+    RT_D uint32_t permuted(uint32_t i) const { return ((global_const_u32*)perm)[i]; }
 };
 struct PerlinLds {
     lds_const_float4v* vecs;
@@ -686,10 +690,10 @@ RT_D float3 texture_value_slow(const DScene& sc, uint32_t tex_id, HitGeom& g, Pe
         size_t at = (size_t)j * im.width + i;
         float3 px;
         if (im.format == RT_IMAGE_RGB8) {
-            uchar4 c = ((const uchar4*)im.texels)[at];
-            px = f3((float)c.x / 255.0f, (float)c.y / 255.0f, (float)c.z / 255.0f);
+            const uint32_t c = ((global_const_u32*)im.texels)[at];  // uchar4: r, g, b, unused
+            px = f3((float)(c & 0xFFu) / 255.0f, (float)((c >> 8) & 0xFFu) / 255.0f, (float)((c >> 16) & 0xFFu) / 255.0f);
         } else {
-            px = f3(((const float4*)im.texels)[at]);
+            px = f3(f4(((global_const_float4v*)im.texels)[at]));
         }
         return px * px;
     }
