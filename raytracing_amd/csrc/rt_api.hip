@@ -285,7 +285,7 @@ int validate(const rt_scene_desc* d) {
     if (d->n_materials == 0) return fail(RT_ERR_INVALID_ARGUMENT, "scene needs at least the default material (MaterialId 0)");
     if (d->n_spheres >= MAX_PRIMS_PER_KIND || d->n_moving_spheres >= MAX_PRIMS_PER_KIND || d->n_quads >= MAX_PRIMS_PER_KIND ||
         d->n_media >= MAX_PRIMS_PER_KIND)
-        return fail(RT_ERR_UNSUPPORTED, "more than 2^28 primitives of one kind");
+        return fail(RT_ERR_UNSUPPORTED, "more than 2^25 primitives of one kind");
     auto need = [&](const void* p, uint32_t n, const char* what) { return n == 0 || p != nullptr ? 0 : fail(RT_ERR_INVALID_ARGUMENT, "%s is NULL but its count is %u", what, n); };
     int e;
     if ((e = need(d->spheres, d->n_spheres, "spheres"))) return e;
@@ -724,7 +724,10 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     for (uint32_t i = 0; i < desc->n_world; ++i) {
         const rt_prim_ref& w = desc->world[i];
         const Aabb& b = box_of(w);
-        uint32_t ref = make_leaf(w.kind, w.index, placed(w));
+        // the reference carries the leaf's shading class (bits 0..7 of the fourth word of its meta record)
+        const uint4* meta_of_kind = w.kind == RT_PRIM_SPHERE ? sphere_meta.data() : w.kind == RT_PRIM_MOVING_SPHERE ? moving_meta.data()
+                                  : w.kind == RT_PRIM_QUAD ? quad_meta.data() : medium_meta.data();
+        uint32_t ref = make_leaf(w.kind, w.index, placed(w), meta_of_kind[2 * (size_t)w.index].w & 0xFFu);
         bool eligible = (w.kind == RT_PRIM_MEDIUM || (w.kind == RT_PRIM_SPHERE && !placed(w))) && desc->n_world > 4;
         if (eligible && n_global < 7 && half_area(b) >= 0.25 * half_area(whole)) {
             global_refs[n_global++] = ref;
@@ -890,7 +893,7 @@ int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
 
 int rt_bvh_build_check(const float* boxes, uint32_t n, rt_bvh_report* out) {
     if (!out || (n && !boxes)) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (n >= rt::MAX_PRIMS_PER_KIND) return fail(RT_ERR_UNSUPPORTED, "more than 2^28 leaves");
+    if (n >= rt::MAX_PRIMS_PER_KIND) return fail(RT_ERR_UNSUPPORTED, "more than 2^25 leaves");
     std::vector<BuildPrim> prims(n);
     for (uint32_t i = 0; i < n; ++i) {
         for (int a = 0; a < 3; ++a) { prims[i].bmin[a] = boxes[6 * (size_t)i + a]; prims[i].bmax[a] = boxes[6 * (size_t)i + 3 + a]; }

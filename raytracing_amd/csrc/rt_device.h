@@ -14,18 +14,23 @@ namespace rt {
 // ---------------------------------------------------------------------------
 // Leaf / child references.  bit 31 set: leaf, bits 29..30 leaf kind (the
 // rt_prim_kind values), bit 28 "placed" (the leaf is stored in object space and
-// carries a Move/RotateY placement), bits 0..27 index into that kind's array.
-// bit 31 clear: index of an inner BVH node.  REF_NONE: empty slot.
+// carries a Move/RotateY placement), bits 25..27 the shading class of the leaf's material
+// (CLS_* below: shade sorts hits by it straight from the hit record), bits 0..24 index into
+// that kind's array.  bit 31 clear: index of an inner BVH node.  REF_NONE: empty slot.
 // ---------------------------------------------------------------------------
 static constexpr uint32_t REF_LEAF = 0x80000000u;
 static constexpr uint32_t REF_PLACED = 0x10000000u;
 static constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
-static constexpr uint32_t MAX_PRIMS_PER_KIND = 1u << 28;
+static constexpr uint32_t REF_CLASS_SHIFT = 25;
+static constexpr uint32_t MAX_PRIMS_PER_KIND = 1u << REF_CLASS_SHIFT;
 static constexpr uint32_t KIND_SPHERE = 0, KIND_MOVING = 1, KIND_QUAD = 2, KIND_MEDIUM = 3;
-RT_HD uint32_t make_leaf(uint32_t kind, uint32_t index, bool placed) { return REF_LEAF | (kind << 29) | (placed ? REF_PLACED : 0u) | index; }
+RT_HD uint32_t make_leaf(uint32_t kind, uint32_t index, bool placed, uint32_t shading_class = 0) {
+    return REF_LEAF | (kind << 29) | (placed ? REF_PLACED : 0u) | (shading_class << REF_CLASS_SHIFT) | index;
+}
 RT_HD bool ref_is_leaf(uint32_t r) { return (r & REF_LEAF) != 0; }
 RT_HD uint32_t ref_kind(uint32_t r) { return (r >> 29) & 3u; }
-RT_HD uint32_t ref_index(uint32_t r) { return r & 0x0FFFFFFFu; }
+RT_HD uint32_t ref_class(uint32_t r) { return (r >> REF_CLASS_SHIFT) & 7u; }
+RT_HD uint32_t ref_index(uint32_t r) { return r & (MAX_PRIMS_PER_KIND - 1u); }
 RT_HD bool ref_placed(uint32_t r) { return (r & REF_PLACED) != 0; }
 
 // ---------------------------------------------------------------------------

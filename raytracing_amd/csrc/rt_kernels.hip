@@ -92,8 +92,7 @@ RT_D void ray_to_object(const DScene& sc, uint32_t xf, float3& o, float3& d) {
 }
 // The way back for a hit record (src/math/ray.rs:75-105): rotate point and normal,
 // then add the offset to the point.
-RT_D void hit_to_world(const DScene& sc, uint32_t xf, float3& p, float3& n) {
-    float4 rot = sc.xforms[2 * (size_t)xf], off = sc.xforms[2 * (size_t)xf + 1];
+RT_D void hit_to_world(float4 rot, float4 off, float3& p, float3& n) {
     float s = rot.x, c = rot.y;
     p = f3((c * p.x) + (s * p.z), p.y, (-s * p.x) + (c * p.z)) + f3(off);
     n = f3((c * n.x) + (s * n.z), n.y, (-s * n.x) + (c * n.z));
@@ -504,63 +503,61 @@ RT_D void set_face_normal(HitGeom& g, float3 d, float3 outward) {  // src/hittab
     g.normal = g.front_face ? outward : -outward;
 }
 
-RT_D HitGeom resolve_hit(const DScene& sc, uint32_t ref, float3 o, float3 d, float time, float t) {
+// m0: the first word group of the leaf's meta record (material, prim_id, transform, class).  Everything read here
+// depends on the leaf reference only, so the loads go out together: the placement comes from the per-leaf copy.
+RT_D HitGeom resolve_hit(const DScene& sc, uint32_t ref, const uint4& m0, float3 o, float3 d, float time, float t) {
     HitGeom g;
     g.u = 0.0f;
     g.v = 0.0f;
     g.uv_ready = true;
     g.uv_dir = f3(0, 0, 0);
+    g.material = m0.x;
+    g.prim_id = m0.y;
     uint32_t kind = ref_kind(ref), idx = ref_index(ref);
     if (kind == KIND_MEDIUM) {  // src/math/ray.rs:153-159
-        DMedium m = sc.media[idx];
         g.p = o + t * d;
         g.normal = f3(1.0f, 0.0f, 0.0f);
         g.front_face = true;
-        g.material = m.phase_material;
-        g.prim_id = m.prim_id;
         return g;
     }
-    uint32_t xf = 0xFFFFFFFFu;
+    const bool placed = ref_placed(ref);
+    float4 rot = make_float4(0, 0, 0, 0), off = rot;
     if (kind == KIND_QUAD) {
         const float4* q4 = sc.quads + 4 * (size_t)idx;
         float4 nd = q4[0], qq = q4[1], A = q4[2], B = q4[3];
-        if (ref_placed(ref)) {
-            xf = __float_as_uint(B.w);
-            ray_to_object(sc, xf, o, d);
+        if (placed) {
+            rot = sc.quad_xf[2 * (size_t)idx]; off = sc.quad_xf[2 * (size_t)idx + 1];
+            ray_to_object(rot, off, o, d);
         }
         g.p = o + t * d;
         float3 h = g.p - f3(qq);
         g.u = dot3(h, f3(A));
         g.v = dot3(h, f3(B));
         set_face_normal(g, d, f3(nd));
-        g.material = __float_as_uint(qq.w);
-        g.prim_id = __float_as_uint(A.w);
     } else {
         float3 c;
         float r;
-        uint4 meta;
+        const float4* xf;
         if (kind == KIND_SPHERE) {
             float4 s = sc.spheres[idx];
             c = f3(s); r = s.w;
-            meta = sc.sphere_meta[2 * (size_t)idx];
+            xf = sc.sphere_xf + 2 * (size_t)idx;
         } else {
             float4 s0 = sc.moving[2 * (size_t)idx], s1 = sc.moving[2 * (size_t)idx + 1];
             c = f3(s0) + time * f3(s1); r = s0.w;
-            meta = sc.moving_meta[2 * (size_t)idx];
+            xf = sc.moving_xf + 2 * (size_t)idx;
         }
-        if (ref_placed(ref)) {
-            xf = meta.z;
-            ray_to_object(sc, xf, o, d);
+        if (placed) {
+            rot = xf[0]; off = xf[1];
+            ray_to_object(rot, off, o, d);
         }
         g.p = o + t * d;
         float3 outward = (1.0f / r) * (g.p - c);
         set_face_normal(g, d, outward);
-        g.material = meta.x;
-        g.prim_id = meta.y;
         g.uv_dir = outward;  // object space, as get_sphere_uv sees it (src/hittable.rs:284)
         g.uv_ready = false;
     }
-    if (xf != 0xFFFFFFFFu) hit_to_world(sc, xf, g.p, g.normal);
+    if (placed) hit_to_world(rot, off, g.p, g.normal);
     return g;
 }
 
@@ -1127,7 +1124,7 @@ RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, ui
     const uint4* meta = leaf_meta(sc, h.y);
     uint4 m0 = meta[0], m1 = meta[1];
     float3 o = f3(ro), d = f3(rd);
-    HitGeom g = resolve_hit(sc, h.y, o, d, ro.w, __uint_as_float(h.x));
+    HitGeom g = resolve_hit(sc, h.y, m0, o, d, ro.w, __uint_as_float(h.x));
     ShadeRec rec = shade_rec_of_leaf(sc, m0, m1);
     uint32_t s_local = path / b.n_pixels;
     Rng rng;
@@ -1201,7 +1198,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
             uint32_t c = N_SHADE_CLASSES;  // no entry
             if (e < tile_n) {
                 uint32_t ref = hits[tile + e].y;
-                c = ref == REF_NONE ? CLS_MISS : (leaf_meta(sc, ref)->w & 0xFFu);
+                c = ref == REF_NONE ? CLS_MISS : ref_class(ref);
             }
             cls[k] = c;
             pos[k] = 0;
@@ -1290,7 +1287,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_unsorted(DScene sc, DCame
             float4 no, nd, nt;
             if (i < n) {
                 uint2 h = hits[i];
-                textured = h.y != REF_NONE && (leaf_meta(sc, h.y)->w & 0xFFu) == CLS_TEXTURED;
+                textured = h.y != REF_NONE && ref_class(h.y) == CLS_TEXTURED;
                 if (!textured) alive = shade_one<false>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], load_thr(thr, i), h, radiance, no, nd, nt);
             }
             unsigned long long mask = __ballot(alive), tmask = __ballot(textured);
@@ -1434,7 +1431,7 @@ __global__ __launch_bounds__(256) void k_intersect(DScene sc, uint64_t seed, con
         uint32_t ref = closest_hit<false>(sc, o, d, r.time, r.tmin, r.tmax, key, t, pr);
         rt_hit h = rt_hit{};
         if (ref != REF_NONE) {
-            HitGeom g = resolve_hit(sc, ref, o, d, r.time, t);
+            HitGeom g = resolve_hit(sc, ref, leaf_meta(sc, ref)[0], o, d, r.time, t);
             ensure_uv(g);
             h.t = t;
             h.point[0] = g.p.x; h.point[1] = g.p.y; h.point[2] = g.p.z;
