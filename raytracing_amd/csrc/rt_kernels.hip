@@ -1178,13 +1178,23 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
                                                        const uint2* __restrict__ hits, float4* __restrict__ out_o,
                                                        float4* __restrict__ out_d, float* __restrict__ out_thr,
                                                        float4* __restrict__ radiance) {
-    __shared__ float4 s_out[3][SHADE_TILE];
-    __shared__ uint16_t s_order[SHADE_TILE];
+    __shared__ float4 s_out[2][SHADE_TILE];        // new rays: origin + time, direction + path
+    __shared__ float s_out_thr[3 * SHADE_TILE];    //           throughput
+    __shared__ uint16_t s_order[SHADE_TILE];       // tile entries in class order
+    __shared__ uint32_t s_ref[SHADE_TILE];         // and their leaf references
     __shared__ uint32_t s_count[N_SHADE_CLASSES];
     __shared__ uint32_t s_offset[N_SHADE_CLASSES + 1];
     __shared__ uint32_t s_alive, s_base, s_tex_base;
     const uint32_t n = counts[bounce];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
+    // leaf references of this thread's entries of the block's first tile (those of the next tile are fetched while the
+    // current tile's rays leave: one memory round trip less in every tile's chain)
+    uint32_t ref_in[SHADE_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < SHADE_PER_THREAD; ++k) {
+        const uint32_t e0 = blockIdx.x * SHADE_TILE + k * SHADE_BLOCK + tid;
+        ref_in[k] = e0 < n ? hits[e0].y : REF_NONE;
+    }
     for (uint32_t tile = blockIdx.x * SHADE_TILE; tile < n; tile += gridDim.x * SHADE_TILE) {
         const uint32_t tile_n = min((uint32_t)SHADE_TILE, n - tile);
         if (tid < N_SHADE_CLASSES) s_count[tid] = 0;
@@ -1196,10 +1206,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
         for (int k = 0; k < SHADE_PER_THREAD; ++k) {
             uint32_t e = k * SHADE_BLOCK + tid;
             uint32_t c = N_SHADE_CLASSES;  // no entry
-            if (e < tile_n) {
-                uint32_t ref = hits[tile + e].y;
-                c = ref == REF_NONE ? CLS_MISS : ref_class(ref);
-            }
+            if (e < tile_n) c = ref_in[k] == REF_NONE ? CLS_MISS : ref_class(ref_in[k]);
             cls[k] = c;
             pos[k] = 0;
             for (uint32_t q = 0; q < N_SHADE_CLASSES; ++q) {
@@ -1224,7 +1231,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < SHADE_PER_THREAD; ++k)
-            if (cls[k] < N_SHADE_CLASSES) s_order[s_offset[cls[k]] + pos[k]] = (uint16_t)(k * SHADE_BLOCK + tid);
+            if (cls[k] < N_SHADE_CLASSES) {
+                const uint32_t dst = s_offset[cls[k]] + pos[k];
+                s_order[dst] = (uint16_t)(k * SHADE_BLOCK + tid);
+                s_ref[dst] = ref_in[k];
+            }
         __syncthreads();
         const uint32_t first_textured = s_offset[CLS_TEXTURED];
 
@@ -1234,8 +1245,14 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
             float4 no, nd, nt;
             if (e < tile_n) {
                 const uint32_t i = tile + s_order[e];
-                if (e >= first_textured) tex_list[s_tex_base + (e - first_textured)] = i;
-                else alive = shade_one<false>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], load_thr(thr, i), hits[i], radiance, no, nd, nt);
+                if (e >= first_textured) {
+                    tex_list[s_tex_base + (e - first_textured)] = i;
+                } else {
+                    // the leaf reference comes from LDS, so the ray, the hit distance, the leaf's records and its
+                    // primitive are all fetched at once
+                    const uint2 h = make_uint2(hits[i].x, s_ref[e]);
+                    alive = shade_one<false>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], load_thr(thr, i), h, radiance, no, nd, nt);
+                }
             }
             unsigned long long mask = __ballot(alive);
             if (mask) {
@@ -1246,8 +1263,19 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
                     uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
                     s_out[0][slot] = no;
                     s_out[1][slot] = nd;
-                    s_out[2][slot] = nt;
+                    s_out_thr[3 * slot] = nt.x;
+                    s_out_thr[3 * slot + 1] = nt.y;
+                    s_out_thr[3 * slot + 2] = nt.z;
                 }
+            }
+        }
+        // the next tile's leaf references, on their way while this tile's rays are written out
+        {
+            const uint32_t next_tile = tile + gridDim.x * SHADE_TILE;
+#pragma unroll
+            for (int k = 0; k < SHADE_PER_THREAD; ++k) {
+                const uint32_t e1 = next_tile + k * SHADE_BLOCK + tid;
+                ref_in[k] = (next_tile < n && e1 < n) ? hits[e1].y : REF_NONE;
             }
         }
         __syncthreads();
@@ -1258,7 +1286,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
         for (uint32_t j = tid; j < n_alive; j += SHADE_BLOCK) {
             out_o[base + j] = s_out[0][j];
             out_d[base + j] = s_out[1][j];
-            store_thr(out_thr, base + j, s_out[2][j]);
+            store_thr(out_thr, base + j, make_float4(s_out_thr[3 * j], s_out_thr[3 * j + 1], s_out_thr[3 * j + 2], 0.0f));
         }
         __syncthreads();
     }
