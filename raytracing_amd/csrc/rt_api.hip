@@ -699,7 +699,12 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         const rt_medium& m = desc->media[i];
         if (m.n_boundary != 1 || desc->boundary[m.first_boundary].kind != RT_PRIM_SPHERE || placed(desc->boundary[m.first_boundary]))
             media_are_single_spheres = false;
-        media[i] = DMedium{m.first_boundary, m.n_boundary, m.neg_inv_density, m.phase_material, m.prim_id, {0, 0, 0}};
+        media[i] = DMedium{m.first_boundary, m.n_boundary, m.neg_inv_density, m.phase_material, m.prim_id, 0u, {0, 0}, make_float4(0, 0, 0, 0)};
+        if (m.n_boundary == 1 && desc->boundary[m.first_boundary].kind == RT_PRIM_SPHERE && !placed(desc->boundary[m.first_boundary])) {
+            const rt_sphere& bs = desc->spheres[desc->boundary[m.first_boundary].index];
+            media[i].single_sphere = 1u;
+            media[i].sphere = make_float4(bs.centre[0], bs.centre[1], bs.centre[2], bs.radius);
+        }
         fill_meta(&medium_meta[2 * (size_t)i], m.phase_material, m.prim_id, RT_NO_TRANSFORM);
         for (uint32_t k = 0; k < m.n_boundary; ++k) medium_box[i].grow(box_of(desc->boundary[m.first_boundary + k]));
     }

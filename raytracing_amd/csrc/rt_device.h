@@ -67,7 +67,9 @@ struct DMedium {
     float neg_inv_density;
     uint32_t phase_material;
     uint32_t prim_id;
-    uint32_t _pad[3];
+    uint32_t single_sphere;  // 1: the boundary is one sphere in world space, repeated below (saves two dependent reads)
+    uint32_t _pad[2];
+    float4 sphere;           // centre.xyz, radius of that sphere
 };
 
 struct DMaterial {

@@ -172,13 +172,12 @@ RT_D bool medium_root(const DScene& sc, uint32_t idx, float3 o, float3 d, float 
     if (COUNT) pr.media++;
     DMedium m = sc.media[idx];
     float t1, t2;
-    const uint32_t ref0 = sc.boundary_refs[m.first_boundary];
-    if (m.n_boundary == 1 && (ref0 >> 28) == (8u | (KIND_SPHERE << 1))) {
+    if (m.single_sphere) {
         // Boundary = one sphere in world space: the two queries share oc, half_b, c and the
         // square root; each root is then chosen exactly as Sphere::hit chooses it for the
         // intervals (-inf, inf) and (0.0001 + t1, inf).
         if (COUNT) pr.spheres += 2;
-        float4 sp = sc.spheres[ref_index(ref0)];
+        float4 sp = m.sphere;
         float3 oc = o - f3(sp);
         float half_b = dot3(oc, d);
         float c = dot3(oc, oc) - sp.w * sp.w;
