@@ -1223,9 +1223,6 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
             uint32_t run = 0;
             for (uint32_t q = 0; q < N_SHADE_CLASSES; ++q) { s_offset[q] = run; run += s_count[q]; }
             s_offset[N_SHADE_CLASSES] = run;
-            // hits on textured materials (the last class) go to this bounce's list: one atomic per tile
-            uint32_t n_tex = s_count[CLS_TEXTURED];
-            s_tex_base = n_tex ? atomicAdd(tex_count, n_tex) : 0u;
         }
         __syncthreads();
 #pragma unroll
@@ -1244,9 +1241,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
             float4 no, nd, nt;
             if (e < tile_n) {
                 const uint32_t i = tile + s_order[e];
-                if (e >= first_textured) {
-                    tex_list[s_tex_base + (e - first_textured)] = i;
-                } else {
+                if (e < first_textured) {
                     // the leaf reference comes from LDS, so the ray, the hit distance, the leaf's records and its
                     // primitive are all fetched at once
                     const uint2 h = make_uint2(hits[i].x, s_ref[e]);
@@ -1278,9 +1273,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
             }
         }
         __syncthreads();
-        const uint32_t n_alive = s_alive;
+        // one atomic per tile appends the new rays to the next queue, another (from another wave, at the same time)
+        // the hits on textured materials - the last class of the sorted tile - to this bounce's list
+        const uint32_t n_alive = s_alive, n_tex = tile_n - first_textured;
         if (tid == 0 && n_alive) s_base = atomicAdd(&counts[bounce + 1], n_alive);
+        if (tid == 64 && n_tex) s_tex_base = atomicAdd(tex_count, n_tex);
         __syncthreads();
+        for (uint32_t j = tid; j < n_tex; j += SHADE_BLOCK) tex_list[s_tex_base + j] = tile + s_order[first_textured + j];
         const uint32_t base = s_base;
         for (uint32_t j = tid; j < n_alive; j += SHADE_BLOCK) {
             out_o[base + j] = s_out[0][j];
