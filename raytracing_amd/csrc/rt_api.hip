@@ -106,7 +106,7 @@ struct rt_scene {
     std::vector<void*> allocations;
     DScene d{};
     uint32_t bvh_depth = 0;
-    bool has_textures = false;  // some material's texture is not a plain colour
+    bool has_textures = false;  // some leaf's material is of the class that k_shade_textured shades
     bool media_are_single_spheres = true;  // every medium's boundary is one unplaced sphere (the short medium test)
     rt_scene_info info{};
 };
@@ -586,7 +586,10 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         const rt_material& mat = desc->materials[material];
         const rt_texture& tex = desc->textures[mat.texture];
         uint32_t cls;
-        if (tex.kind != RT_TEX_SOLID) cls = CLS_TEXTURED;
+        const bool plain_checker = tex.kind == RT_TEX_CHECKER && desc->textures[tex.even].kind == RT_TEX_SOLID &&
+                                   desc->textures[tex.odd].kind == RT_TEX_SOLID;
+        if (plain_checker && mat.kind == RT_MAT_LAMBERTIAN) cls = CLS_CHECKER;
+        else if (tex.kind != RT_TEX_SOLID) cls = CLS_TEXTURED;
         else switch (mat.kind) {
             case RT_MAT_DIFFUSE_LIGHT: cls = CLS_LIGHT; break;
             case RT_MAT_LAMBERTIAN: cls = CLS_LAMBERTIAN; break;
@@ -820,6 +823,16 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     }
     if ((e = upload(sc, materials, &sc->d.materials))) return bail(e);
     if ((e = upload(sc, textures, &sc->d.textures))) return bail(e);
+    {   // the two colours and the scale of every material that shades as CLS_CHECKER
+        std::vector<DChecker> checkers(desc->n_materials, DChecker{0.0f, {0, 0, 0}, {0, 0, 0}, 0.0f});
+        for (uint32_t i = 0; i < desc->n_materials; ++i) {
+            const DTexture& t = textures[desc->materials[i].texture];
+            if (t.kind != RT_TEX_CHECKER || textures[t.even].kind != RT_TEX_SOLID || textures[t.odd].kind != RT_TEX_SOLID) continue;
+            const DTexture &te = textures[t.even], &to = textures[t.odd];
+            checkers[i] = DChecker{t.scale, {te.r, te.g, te.b}, {to.r, to.g, to.b}, 0.0f};
+        }
+        if ((e = upload(sc, checkers, &sc->d.checkers))) return bail(e);
+    }
 
     std::vector<DImage> images(desc->n_images);
     for (uint32_t i = 0; i < desc->n_images; ++i) {
@@ -874,8 +887,10 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     sc->d.n_nodes = bvh.n_nodes;
     sc->d.n_media = desc->n_media;
     sc->d.n_materials = desc->n_materials;
-    for (uint32_t i = 0; i < desc->n_materials; ++i)
-        if (desc->textures[desc->materials[i].texture].kind != RT_TEX_SOLID) sc->has_textures = true;
+    // the second shade kernel is launched only when some leaf's hits are set aside for it
+    for (const std::vector<uint4>* metas : {&sphere_meta, &moving_meta, &quad_meta, &medium_meta})
+        for (size_t i = 0; i < metas->size(); i += 2)
+            if (((*metas)[i].w & 0xFFu) == CLS_TEXTURED) sc->has_textures = true;
     sc->info.bvh_nodes = bvh.n_nodes;
     sc->info.bvh_depth = bvh.max_depth;
     sc->info.leaves_in_tree = (uint32_t)prims.size();

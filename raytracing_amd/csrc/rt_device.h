@@ -88,6 +88,13 @@ struct DTexture {
     uint32_t _pad[3];
 };
 
+// Texture::Checker (src/texture.rs:45-55) whose two sub-textures are plain colours, by material index.
+struct DChecker {
+    float scale;
+    float even[3], odd[3];
+    float _pad;
+};
+
 struct DImage {
     const void* texels;  // uchar4 (RGBX) or float4 per texel
     uint32_t width, height;
@@ -127,6 +134,7 @@ struct DScene {
     const DTexture* textures;
     const DImage* images;
     const DPerlin* perlins;
+    const DChecker* checkers;  // n_materials entries, meaningful for the materials of CLS_CHECKER leaves
     uint32_t root;             // child reference of the tree (REF_NONE when it is empty)
     uint32_t n_nodes;
     uint32_t n_media;
@@ -139,7 +147,9 @@ struct DScene {
 // Shading classes: rays of one class run the same code, so the shade kernel groups the rays of
 // a tile by class before it processes them.
 static constexpr uint32_t CLS_MISS = 0, CLS_LIGHT = 1, CLS_LAMBERTIAN = 2, CLS_METAL = 3, CLS_DIELECTRIC = 4, CLS_ISOTROPIC = 5,
-                          CLS_TEXTURED = 6, N_SHADE_CLASSES = 7;
+                          CLS_CHECKER = 6,   // lambertian whose texture is a checker of two plain colours (DChecker): shaded inline
+                          CLS_TEXTURED = 7,  // every other texture that is not a plain colour: set aside for k_shade_textured (last class)
+                          N_SHADE_CLASSES = 8;
 
 struct DCamera {
     float3 centre, pixel00, du, dv, ddu, ddv, background;

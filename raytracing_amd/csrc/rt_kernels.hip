@@ -1125,6 +1125,12 @@ RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, ui
     float3 o = f3(ro), d = f3(rd);
     HitGeom g = resolve_hit(sc, h.y, m0, o, d, ro.w, __uint_as_float(h.x));
     ShadeRec rec = shade_rec_of_leaf(sc, m0, m1);
+    if (!TEXTURES && ref_class(h.y) == CLS_CHECKER) {  // Texture::Checker over two plain colours (src/texture.rs:45-55)
+        const DChecker ck = sc.checkers[m0.x];
+        const float sum = floorf(ck.scale * g.p.x) + floorf(ck.scale * g.p.y) + floorf(ck.scale * g.p.z);
+        const bool is_even = ((int)sum % 2) == 0;
+        rec.colour = is_even ? f3(ck.even[0], ck.even[1], ck.even[2]) : f3(ck.odd[0], ck.odd[1], ck.odd[2]);
+    }
     uint32_t s_local = path / b.n_pixels;
     Rng rng;
     rng.init(path_key(seed, b.first_pixel + (path - s_local * b.n_pixels), b.first_sample + s_local), bounce, STREAM_SCATTER);
