@@ -305,7 +305,10 @@ int rt_buffer_download(rt_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 
 /* Replaces World::new + the walk a Rust caller would do over its Hittable
  * tree (src/lib.rs:17-26, src/hittable.rs:35-57): copies the description,
- * bakes transforms, builds the flattened BVH and uploads everything. */
+ * bakes transforms, builds the flattened BVH and uploads everything.
+ * Limits (RT_ERR_UNSUPPORTED beyond them): fewer than 2^25 spheres, moving
+ * spheres, quads and media each; noise tables of at most 2^20 points; a tree
+ * whose traversal can need more than 64 stack entries. */
 int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out);
 int rt_scene_destroy(rt_scene* scene);
 
