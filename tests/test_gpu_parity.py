@@ -180,6 +180,9 @@ def _random_scene(s, rng):
     tex.append(s.tex_noise(s.perlin((5, 6, 7, 8), 37), 1.7))
     img = rng.integers(0, 256, (5, 9, 3), dtype=np.uint8)
     tex.append(s.tex_image(img))
+    # a checker whose squares are themselves a checker and a noise texture (a second table: with two tables the kernels
+    # read them from global memory, with one - the built-in scenes - from their LDS copy)
+    tex.append(s.tex_checker(1.3, tex[3], s.tex_noise(s.perlin((9, 10, 11, 12), 256), 0.9)))
     mats = [s.lambertian(t) for t in tex] + [s.metal(tex[0], 0.2), s.metal(tex[3], 1.5), s.dielectric(tex[1], 1.5),
                                              s.diffuse_light(tex[2]), s.diffuse_light(tex[5]), s.isotropic(tex[4])]
     items = []
