@@ -385,6 +385,14 @@ def test_error_reporting_on_bad_input():
         s.shade(np.zeros(1, _abi.ray_dtype()), hits)
     with pytest.raises(rt.RenderError, match="outside"):
         s.primary_rays(np.array([16 * 16], np.uint32), 1)
+    # a noise table beyond the documented limit is refused when the scene is created
+    big = rt.Scene()
+    noisy = big.lambertian(big.tex_noise(big.perlin((1, 2, 3, 4), (1 << 20) + 1), 1.0))
+    big.set_world(big.bvh([big.sphere((0, 0, 0), 1.0, noisy)]))
+    with pytest.raises(rt.RenderError, match="points"):
+        big.camera((0, 0, -5), 8, 8, max_depth=2, vfov=40.0, vup=(0, 1, 0), defocus_angle=0.0, focus_dist=1.0,
+                   background=(0, 0, 0), pitch=0.0, yaw=90.0)
+        big.render_samples(1)
 
 
 def test_bvh_stress_scene_against_oracle():
