@@ -1055,7 +1055,7 @@ int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, ui
             const uint32_t np = (uint32_t)std::min<uint64_t>(chunk_pixels, npix - p0);
             for (uint32_t s0 = 0; s0 < n_samples; s0 += spb, ++batch_no) {
                 const uint32_t ns = std::min(spb, n_samples - s0);
-                BatchInfo b{(uint32_t)(pix0 + p0), np, first_sample + s0, ns};
+                const BatchInfo b = rt::make_batch((uint32_t)(pix0 + p0), np, first_sample + s0, ns);
                 const uint32_t total = np * ns;
                 Pipe& q = c->pipes[batch_no % (uint32_t)n_pipes];
                 hipStream_t st = n_pipes > 1 ? q.stream : c->stream;

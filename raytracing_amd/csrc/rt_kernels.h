@@ -10,9 +10,18 @@ namespace rt {
 
 // One batch of paths: pixels [first_pixel, first_pixel + n_pixels) of the image,
 // sample numbers [first_sample, first_sample + n_samples).
+// A path of the batch is known by its id (s_local << pixel_bits) | pixel_local, carried in the w lane of its ray's
+// direction: sample and pixel come out of it with a shift and a mask, its slot in the radiance array is
+// s_local * n_pixels + pixel_local.
 struct BatchInfo {
     uint32_t first_pixel, n_pixels, first_sample, n_samples;
+    uint32_t pixel_bits;  // smallest number of bits that holds n_pixels - 1
 };
+inline BatchInfo make_batch(uint32_t first_pixel, uint32_t n_pixels, uint32_t first_sample, uint32_t n_samples) {
+    uint32_t bits = 0;
+    while (bits < 32 && (1ull << bits) < n_pixels) ++bits;
+    return BatchInfo{first_pixel, n_pixels, first_sample, n_samples, bits};
+}
 
 // max_blocks caps the grid (grid-stride kernels); upper_bound is a host-side
 // bound on the queue length, the exact length is read from counts[bounce].

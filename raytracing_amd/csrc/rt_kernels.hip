@@ -156,11 +156,10 @@ struct MediumKey {
 };
 struct BatchMediumKey {
     uint64_t seed;
-    uint32_t path, bounce;
+    uint32_t path, bounce;  // path: the path's id in the batch (BatchInfo)
     BatchInfo b;
     RT_D uint64_t path_key_of() const {
-        uint32_t s_local = path / b.n_pixels;
-        return path_key(seed, b.first_pixel + (path - s_local * b.n_pixels), b.first_sample + s_local);
+        return path_key(seed, b.first_pixel + (path & ((1u << b.pixel_bits) - 1u)), b.first_sample + (path >> b.pixel_bits));
     }
 };
 
@@ -865,8 +864,8 @@ RT_D void primary_ray(const DCamera& cam, uint64_t seed, uint32_t pixel, uint32_
     time = rng.next();
 }
 
-// One thread per path of the batch.  Path index = s_local * n_pixels + pixel_local,
-// which is also the initial queue slot.
+// One thread per path of the batch.  s_local * n_pixels + pixel_local is the path's initial queue slot and its
+// slot in the radiance array.
 __global__ __launch_bounds__(256) void k_raygen(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, float4* __restrict__ ray_o,
                                                 float4* __restrict__ ray_d, float* __restrict__ thr, uint2* __restrict__ first_hits,
                                                 uint32_t* __restrict__ counts, uint32_t n_counts) {
@@ -880,7 +879,8 @@ __global__ __launch_bounds__(256) void k_raygen(DScene sc, DCamera cam, BatchInf
         float3 origin, dir;
         float time;
         primary_ray(cam, seed, pixel, b.first_sample + s_local, origin, dir, time);
-        const float4 ro = make_float4(origin.x, origin.y, origin.z, time), rd = make_float4(dir.x, dir.y, dir.z, __uint_as_float(i));
+        const uint32_t id = (s_local << b.pixel_bits) | (i - s_local * b.n_pixels);
+        const float4 ro = make_float4(origin.x, origin.y, origin.z, time), rd = make_float4(dir.x, dir.y, dir.z, __uint_as_float(id));
         ray_o[i] = ro;
         ray_d[i] = rd;
         store_thr(thr, i, make_float4(1.0f, 1.0f, 1.0f, 0.0f));
@@ -1113,7 +1113,9 @@ __global__ __launch_bounds__(256) void k_first_leaves(DScene sc, BatchInfo b, ui
 template <bool TEXTURES>
 RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, uint64_t seed, uint32_t bounce, float4 ro, float4 rd, float4 th,
                     uint2 h, float4* __restrict__ radiance, float4& no, float4& nd, float4& nt, PerlinLds lds_perlin = PerlinLds{nullptr, nullptr, false}) {
-    uint32_t path = __float_as_uint(rd.w);
+    const uint32_t id = __float_as_uint(rd.w);  // (sample of the batch << pixel_bits) | pixel of the batch
+    const uint32_t s_local = id >> b.pixel_bits, pixel_local = id & ((1u << b.pixel_bits) - 1u);
+    const uint32_t path = s_local * b.n_pixels + pixel_local;  // slot in the radiance array
     float3 T = f3(th);
     if (h.y == REF_NONE) {  // src/camera.rs:347-349
         float3 c = T * cam.background;
@@ -1131,9 +1133,8 @@ RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, ui
         const bool is_even = ((int)sum % 2) == 0;
         rec.colour = is_even ? f3(ck.even[0], ck.even[1], ck.even[2]) : f3(ck.odd[0], ck.odd[1], ck.odd[2]);
     }
-    uint32_t s_local = path / b.n_pixels;
     Rng rng;
-    rng.init(path_key(seed, b.first_pixel + (path - s_local * b.n_pixels), b.first_sample + s_local), bounce, STREAM_SCATTER);
+    rng.init(path_key(seed, b.first_pixel + pixel_local, b.first_sample + s_local), bounce, STREAM_SCATTER);
     ScatterResult r = shade_hit<TEXTURES>(sc, rec, g, d, rng, lds_perlin);
     if (!r.scattered) {  // src/camera.rs:354-355
         float3 c = T * r.emitted;
