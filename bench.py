@@ -41,7 +41,7 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=6)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--spp-per-step", type=int, default=16)
+    p.add_argument("--spp-per-step", type=int, default=32)   # two batches of 16 spp (133 M paths each), one per pipeline
     p.add_argument("--width", type=int, default=WIDTH)
     p.add_argument("--height", type=int, default=HEIGHT)
     p.add_argument("--seed", type=int, default=0)
