@@ -158,20 +158,22 @@ def test_image_statistics_match_reference_random_numbers(sid, spp):
         assert abs(c - ref) <= 3.0 * abs(a - b) + 0.005 * ref + 1e-6, (ch, a, b, c)
 
 
-def test_high_sample_count_image_rmse():
-    """Book-1 scene, 2048 samples per pixel on both sides (reference random numbers on the CPU): the sqrt-encoded
-    images agree to an absolute RMSE of 0.01 and no worse than two CPU renders agree with each other."""
+@pytest.mark.parametrize("sid,spp", [(0, 2048), (6, 4096), (8, 4096)])
+def test_high_sample_count_image_rmse(sid, spp):
+    """Book-1 scene, Cornell box and the Book-2 final scene (small images), thousands of samples per pixel on both sides
+    (reference random numbers on the CPU): the sqrt-encoded images agree no worse than two CPU renders agree with
+    each other, and - on the Book-1 scene, whose noise is that low by then - to an absolute RMSE of 0.01 (the small
+    light of the Cornell box and the dark Book-2 scene still have a CPU-to-CPU RMSE of 0.025 - 0.028 at 4096 samples)."""
     w = h = 24
-    spp = 2048
-    scene = rt.Scene.builtin(0, w, h)
-    oracle = ob.OracleScene.builtin(0, w, h)
+    scene = rt.Scene.builtin(sid, w, h)
+    oracle = ob.OracleScene.builtin(sid, w, h)
     scene.render_samples(spp)
     gpu = scene.accumulator()[:, 4:]
     cpu_a = oracle.render(spp, first_sample=1, mode=ob.RNG_XOSHIRO)[:, 4:]
     cpu_b = oracle.render(spp, first_sample=spp + 1, mode=ob.RNG_XOSHIRO)[:, 4:]
     noise = np.sqrt(np.mean((enc(cpu_a, spp) - enc(cpu_b, spp)) ** 2))
     rmse = np.sqrt(np.mean((enc(gpu, spp) - enc(cpu_a, spp)) ** 2))
-    assert rmse <= 0.01 and rmse <= 1.15 * noise, (rmse, noise)
+    assert rmse <= 1.15 * noise and (sid != 0 or rmse <= 0.01), (rmse, noise)
 
 
 def _random_scene(s, rng):
