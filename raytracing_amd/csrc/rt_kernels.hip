@@ -1154,13 +1154,16 @@ RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, ui
 
 // Shade: Material::emitted / scatter for every (ray, hit) of the current queue.
 //
-// A block (512 threads) takes a tile of SHADE_TILE = 1024 consecutive queue slots, reads their hit records, looks up
-// each leaf's shading class (one cached 16-byte read) and counting-sorts the tile by class in
-// LDS.  The threads then walk the tile in sorted order, so that the 64 lanes of a wave run the
-// same material code on (almost always) the same class; the ray records they read all lie inside
-// the tile, i.e. in cache lines the block consumes completely.  Hits on materials whose texture
-// is not a plain colour (checker, image, perlin noise) are only listed here; k_shade_textured
-// handles them, which keeps the register footprint of this kernel small.
+// A block (512 threads) takes a tile of SHADE_TILE = 1024 consecutive queue slots, reads the leaf references of
+// their hit records (the shading class of the leaf's material sits in bits of the reference) and counting-sorts
+// the tile by class in LDS.  The threads then walk the tile in sorted order, so that the 64 lanes of a wave run
+// the same material code on (almost always) the same class; the ray records they read all lie inside the tile,
+// i.e. in cache lines the block consumes completely.  A tile's time is a chain of dependent memory round trips,
+// so whatever can be fetched together is: the sorted references travel through LDS (ray, hit distance, the leaf's
+// records, its primitive and placement then go out in one round trip), and the next tile's references are
+// fetched while this tile's rays leave.  Hits on materials whose texture is an image, a noise or a checker of
+// those are only listed here; k_shade_textured handles them, which keeps the register footprint of this kernel
+// small (a checker of two plain colours is a class of its own and is shaded here).
 // Measured on the headline scene (shade time per 16 samples): tiles of 256 / 512 / 1024 / 2048 slots take
 // 36.7 / 23.8 / 22.9 / 26.6 ms - small tiles are bound by the queue atomic, large ones by LDS per block.
 #ifndef RT_SHADE_BLOCK
