@@ -260,7 +260,10 @@ typedef struct rt_counters {
     uint64_t quad_tests;
     uint64_t medium_tests;
     uint64_t hits;           /* segments that hit something                   */
-    uint64_t _pad;
+    uint64_t max_stack;      /* deepest traversal stack of any ray (entries): a
+                                maximum, not a sum; beyond the extend kernel's
+                                LDS levels (8 when the whole tree is copied to
+                                LDS, else 12) the global overflow area was used */
 } rt_counters;
 
 typedef enum rt_finalize_mode {
@@ -387,6 +390,22 @@ int rt_finalize(rt_ctx* ctx, const float* acc_host, uint64_t n_pixels,
  * blocking.  seed keys the medium free-path draw as in rt_render_*. */
 int rt_intersect_batch(rt_scene* scene, const rt_ray* rays, size_t n,
                        uint64_t seed, rt_hit* out);
+
+/* Ray::hit_anything (src/math/ray.rs:59-275) once more, computed by the kernels
+ * of the render path itself: the rays are put into a ray queue and go through
+ * the pass over the leaves kept out of the tree and the extend kernel exactly
+ * as the rays of rt_render_accumulate* do (persistent waves, traversal stack in
+ * LDS with its overflow area in global memory, the tree in LDS when it is small),
+ * whereas rt_intersect_batch walks the same tree with one thread per ray and a
+ * private stack.  Results must be identical; the call exists so that the
+ * render path's traversal can be checked ray by ray.  Every ray must carry the
+ * interval the render path uses, tmin = 0.001 and tmax = +inf, and
+ * (rng_sample << bits(rng_pixel)) must fit 32 bits, rng_bounce <= 4096
+ * (RT_ERR_INVALID_ARGUMENT / RT_ERR_UNSUPPORTED otherwise).  With the work
+ * counters on, rt_counters.max_stack tells how deep the stacks got.  Host
+ * buffers, blocking. */
+int rt_extend_batch(rt_scene* scene, const rt_ray* rays, size_t n,
+                    uint64_t seed, rt_hit* out);
 
 /* Replaces Material::emitted + Material::scatter (src/material.rs:65-122, with
  * Texture::value, src/texture.rs:40-73) on caller-supplied (ray, hit record)

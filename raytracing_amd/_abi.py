@@ -44,7 +44,7 @@ class RtCameraDesc(C.Structure):
 
 class RtCounters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("node_visits", C.c_uint64), ("sphere_tests", C.c_uint64),
-                ("quad_tests", C.c_uint64), ("medium_tests", C.c_uint64), ("hits", C.c_uint64), ("_pad", C.c_uint64)]
+                ("quad_tests", C.c_uint64), ("medium_tests", C.c_uint64), ("hits", C.c_uint64), ("max_stack", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if not k.startswith("_")}
@@ -120,6 +120,7 @@ RT_ABI = {
     "rt_finalize_device": (C.c_int, [_P, _P, _U64, _U32, C.c_int, _F, _P]),
     "rt_finalize": (C.c_int, [_P, _P, _U64, _U32, C.c_int, _F, _P]),
     "rt_intersect_batch": (C.c_int, [_P, _P, C.c_size_t, _U64, _P]),
+    "rt_extend_batch": (C.c_int, [_P, _P, C.c_size_t, _U64, _P]),
     "rt_shade_batch": (C.c_int, [_P, _P, _P, C.c_size_t, _U64, _P, _P, _P]),
     "rt_primary_rays": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _P, C.c_size_t, _P]),
     "rt_ctx_synchronize": (C.c_int, [_P]),

@@ -106,6 +106,7 @@ struct rt_scene {
     std::vector<void*> allocations;
     DScene d{};
     uint32_t bvh_depth = 0;
+    uint32_t stack_need = 0;    // traversal stack entries the tree can need in the worst case
     bool has_textures = false;  // some leaf's material is of the class that k_shade_textured shades
     bool media_are_single_spheres = true;  // every medium's boundary is one unplaced sphere (the short medium test)
     rt_scene_info info{};
@@ -135,7 +136,8 @@ void free_queues(Pipe& p) {
     p.cap = 0;
 }
 
-int ensure_queues(rt_ctx* c, Pipe& p, uint64_t paths, uint32_t n_counts) {
+// need_overflow: the scene's tree can stack more entries than the extend kernel keeps in LDS
+int ensure_queues(rt_ctx* c, Pipe& p, uint64_t paths, uint32_t n_counts, bool need_overflow) {
     if (paths > p.cap) {
         free_queues(p);
         for (int i = 0; i < 2; ++i) {
@@ -154,7 +156,7 @@ int ensure_queues(rt_ctx* c, Pipe& p, uint64_t paths, uint32_t n_counts) {
         HIP_TRY(hipMalloc((void**)&p.counts, n_counts * sizeof(uint32_t)));
         p.counts_cap = n_counts;
     }
-    if (!p.stack_overflow) HIP_TRY(hipMalloc((void**)&p.stack_overflow, rt::extend_overflow_bytes(c->extend_blocks)));
+    if (need_overflow && !p.stack_overflow) HIP_TRY(hipMalloc((void**)&p.stack_overflow, rt::extend_overflow_bytes(c->extend_blocks)));
     if (!p.done) HIP_TRY(hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     if (!p.stream && c->n_pipes > 1) HIP_TRY(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     return RT_OK;
@@ -362,6 +364,8 @@ int validate(const rt_scene_desc* d) {
     }
     return RT_OK;
 }
+
+bool needs_overflow(const rt_scene* sc) { return sc->stack_need > (uint32_t)rt::extend_lds_stack_levels(sc->d.n_nodes); }
 
 DCamera to_dcamera(const rt_camera_desc* c) {
     DCamera d;
@@ -786,6 +790,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     rt_scene* sc = new rt_scene();
     sc->ctx = ctx;
     sc->bvh_depth = bvh.max_depth;
+    sc->stack_need = bvh.stack_need;
     sc->media_are_single_spheres = media_are_single_spheres;
     auto bail = [&](int code) { rt_scene_destroy(sc); return code; };
 
@@ -1038,7 +1043,7 @@ int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, ui
     const uint32_t n_queue_counts = cam->max_depth + 2;
     const uint32_t n_counts = 2 * cam->max_depth + 2;
     for (int i = 0; i < n_pipes; ++i)
-        if ((e = ensure_queues(c, c->pipes[i], (uint64_t)chunk_pixels * spb, n_counts))) return e;
+        if ((e = ensure_queues(c, c->pipes[i], (uint64_t)chunk_pixels * spb, n_counts, needs_overflow(sc)))) return e;
     DCamera dcam = to_dcamera(cam);
     DCounters* counters = c->counters_on ? c->d_counters : nullptr;
     rt::ExtendTuning tune = c->tune;
@@ -1201,6 +1206,76 @@ int rt_intersect_batch(rt_scene* sc, const rt_ray* rays, size_t n, uint64_t seed
     (void)hipFree(d_rays);
     (void)hipFree(d_hits);
     if (he != hipSuccess || hs != hipSuccess) return fail(RT_ERR_HIP, "intersect failed: %s", hipGetErrorString(he != hipSuccess ? he : hs));
+    return RT_OK;
+}
+
+int rt_extend_batch(rt_scene* sc, const rt_ray* rays, size_t n, uint64_t seed, rt_hit* out) {
+    if (!sc || (n && (!rays || !out))) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n == 0) return RT_OK;
+    if (n >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "more than 2^31 rays");
+    rt_ctx* c = sc->ctx;
+    int e = set_device(c);
+    if (e) return e;
+    // the render path's interval, and path ids that hold (rng_pixel, rng_sample) in 32 bits
+    uint32_t max_pixel = 0, max_sample = 0, max_bounce = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (rays[i].tmin != 0.001f || rays[i].tmax != INFINITY)
+            return fail(RT_ERR_INVALID_ARGUMENT, "rays[%zu]: the render path casts every ray over (0.001, +inf)", i);
+        max_pixel = std::max(max_pixel, rays[i].rng_pixel);
+        max_sample = std::max(max_sample, rays[i].rng_sample);
+        max_bounce = std::max(max_bounce, rays[i].rng_bounce);
+    }
+    uint32_t pixel_bits = 0;
+    while (pixel_bits < 32 && (1ull << pixel_bits) <= max_pixel) ++pixel_bits;
+    if (pixel_bits >= 32 || ((uint64_t)max_sample << pixel_bits) > 0xFFFFFFFFull)
+        return fail(RT_ERR_UNSUPPORTED, "rng_pixel (max %u) and rng_sample (max %u) do not fit one 32-bit path id", max_pixel, max_sample);
+    if (max_bounce > 4096) return fail(RT_ERR_UNSUPPORTED, "rng_bounce above 4096");
+    // one launch per bounce number: rays grouped by rng_bounce (stable), results scattered back afterwards
+    std::vector<uint32_t> group_size(max_bounce + 1, 0), group_at(max_bounce + 2, 0);
+    for (size_t i = 0; i < n; ++i) group_size[rays[i].rng_bounce]++;
+    for (uint32_t b = 0; b <= max_bounce; ++b) group_at[b + 1] = group_at[b] + group_size[b];
+    std::vector<uint32_t> slot_of(n), fill(group_at.begin(), group_at.end() - 1);
+    std::vector<rt_ray> grouped(n);
+    for (size_t i = 0; i < n; ++i) {
+        slot_of[i] = fill[rays[i].rng_bounce]++;
+        grouped[slot_of[i]] = rays[i];
+    }
+    Pipe& q = c->pipes[0];
+    if ((e = ensure_queues(c, q, n, max_bounce + 1, needs_overflow(sc)))) return e;
+    rt_ray* d_rays = nullptr;
+    rt_hit* d_hits = nullptr;
+    std::vector<rt_hit> grouped_out(n);
+    HIP_TRY(hipMalloc((void**)&d_rays, n * sizeof(rt_ray)));
+    hipError_t he = hipMalloc((void**)&d_hits, n * sizeof(rt_hit));
+    if (he != hipSuccess) { (void)hipFree(d_rays); return fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc failed: %s", hipGetErrorString(he)); }
+    hipStream_t st = c->stream;
+    he = hipMemcpyAsync(d_rays, grouped.data(), n * sizeof(rt_ray), hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(q.counts, group_size.data(), (max_bounce + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) {
+        DCounters* counters = c->counters_on ? c->d_counters : nullptr;
+        rt::ExtendTuning tune = c->tune;
+        if (tune.medium_min <= 0) tune.medium_min = sc->media_are_single_spheres ? 4 : 24;
+        const BatchInfo b{0u, pixel_bits == 0 ? 1u : (pixel_bits >= 31 ? 0x7FFFFFFFu : (1u << pixel_bits)), 0u, max_sample + 1u, pixel_bits};
+        launch_pack_rays(st, c->max_blocks, d_rays, n, pixel_bits, q.ray_o[0], q.ray_d[0]);
+        for (uint32_t bounce = 0; bounce <= max_bounce; ++bounce) {
+            if (group_size[bounce] == 0) continue;
+            const size_t at = group_at[bounce];
+            // the kernels read their queue length from counts[bounce]: the queue of this group starts at `at`
+            if (sc->d.n_global != 0)
+                launch_first_leaves(st, c->max_blocks, group_size[bounce], sc->d, b, seed, bounce, q.counts, q.ray_o[0] + at, q.ray_d[0] + at,
+                                    q.hits + at, counters);
+            launch_extend(st, counters ? c->extend_blocks_counting : c->extend_blocks, group_size[bounce], sc->d, b, seed, bounce, q.counts,
+                          q.ray_o[0] + at, q.ray_d[0] + at, q.hits + at, q.stack_overflow, tune, counters);
+        }
+        launch_unpack_hits(st, c->max_blocks, sc->d, d_rays, q.hits, n, d_hits);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(grouped_out.data(), d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, st);
+    hipError_t hs = hipStreamSynchronize(st);
+    (void)hipFree(d_rays);
+    (void)hipFree(d_hits);
+    if (he != hipSuccess || hs != hipSuccess) return fail(RT_ERR_HIP, "extend failed: %s", hipGetErrorString(he != hipSuccess ? he : hs));
+    for (size_t i = 0; i < n; ++i) out[i] = grouped_out[slot_of[i]];
     return RT_OK;
 }
 

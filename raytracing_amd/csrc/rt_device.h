@@ -158,7 +158,8 @@ struct DCamera {
 };
 
 struct DCounters {
-    unsigned long long samples, segments, node_visits, sphere_tests, quad_tests, medium_tests, hits, _pad;
+    unsigned long long samples, segments, node_visits, sphere_tests, quad_tests, medium_tests, hits;
+    unsigned long long max_stack;  // deepest traversal stack any ray of the extend kernel has had (entries)
 };
 
 // ---------------------------------------------------------------------------

@@ -41,6 +41,8 @@ struct ExtendTuning {
                           // of leaves, whose test runs to several hundred instructions)
 };
 int extend_blocks_per_cu(bool counting);
+// stack levels per lane the extend kernel keeps in LDS for a tree of n_nodes nodes; deeper levels go to the overflow area
+int extend_lds_stack_levels(uint32_t n_nodes);
 size_t extend_overflow_bytes(uint32_t blocks);
 // The same computation as a pass of its own over a queue.
 void launch_first_leaves(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
@@ -60,6 +62,11 @@ void launch_finalize(hipStream_t st, uint32_t max_blocks, const float4* acc, uns
                      float exposure, void* out);
 void launch_intersect(hipStream_t st, uint32_t max_blocks, const DScene& sc, uint64_t seed, const rt_ray* rays, unsigned long long n,
                       rt_hit* out);
+// caller-supplied rays into / hit records out of the queue layout (the extend kernel on its own, for parity checks)
+void launch_pack_rays(hipStream_t st, uint32_t max_blocks, const rt_ray* rays, unsigned long long n, uint32_t pixel_bits, float4* ray_o,
+                      float4* ray_d);
+void launch_unpack_hits(hipStream_t st, uint32_t max_blocks, const DScene& sc, const rt_ray* rays, const uint2* hits, unsigned long long n,
+                        rt_hit* out);
 void launch_shade_records(hipStream_t st, uint32_t max_blocks, const DScene& sc, uint64_t seed, const rt_ray* rays, const rt_hit* hits,
                           unsigned long long n, rt_ray* out_rays, float* out_att, float* out_emit);
 

@@ -77,6 +77,7 @@ RT_D bool quad_root(const float4* __restrict__ q4, float3 o, float3 d, float tmi
 
 struct Probe {  // per-thread work counters (only live in the counting build)
     uint32_t nodes = 0, spheres = 0, quads = 0, media = 0;
+    uint32_t max_sp = 0;  // deepest traversal stack this lane has had
 };
 
 // Move { RotateY { obj } } entry (src/math/ray.rs:207-229): origin - offset, then
@@ -804,6 +805,9 @@ RT_D ScatterResult shade_hit(const DScene& sc, const ShadeRec& m, HitGeom& g, fl
 // ---------------------------------------------------------------------------
 // counters
 // ---------------------------------------------------------------------------
+#ifndef RT_LANE_STATS
+#define RT_LANE_STATS 0  // development builds: 1..6 count the lane slots of one loop part of k_extend in DCounters::max_stack
+#endif
 RT_D unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -811,10 +815,19 @@ RT_D unsigned long long wave_sum(unsigned long long v) {
 }
 
 RT_D void flush_probe(DCounters* c, const Probe& pr, uint32_t segments, uint32_t hits, uint32_t slots = 0) {
-    if (slots) {
+#if RT_LANE_STATS != 0
+    if (slots) {  // development builds reuse the field for the lane-slot count of one loop part
         unsigned long long sl = wave_sum(slots);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&c->_pad, sl);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&c->max_stack, sl);
     }
+#else
+    {
+        uint32_t deepest = pr.max_sp;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) deepest = max(deepest, (uint32_t)__shfl_down((int)deepest, off, 64));
+        if ((threadIdx.x & 63) == 0 && deepest != 0) atomicMax(&c->max_stack, (unsigned long long)deepest);
+    }
+#endif
     unsigned long long n = wave_sum(pr.nodes), s = wave_sum(pr.spheres), q = wave_sum(pr.quads), m = wave_sum(pr.media);
     unsigned long long sg = wave_sum(segments), h = wave_sum(hits);
     if ((threadIdx.x & 63) == 0) {
@@ -914,9 +927,6 @@ __global__ __launch_bounds__(256) void k_primary_rays(DCamera cam, uint64_t seed
 // one), testing the sphere / quad leaves lanes have arrived at, and testing media.  The medium
 // test is by far the longest, so lanes that arrive at a medium wait there until MEDIUM_MIN of
 // them have gathered (or nothing else is left to do).
-#ifndef RT_LANE_STATS
-#define RT_LANE_STATS 0  // development builds: 1..6 count the lane slots of one state of k_extend in DCounters::_pad
-#endif
 static constexpr int EXTEND_BLOCK = 256;
 
 // LDS of one block: 24 KiB, spent either on 12 stack levels per lane, or - for a tree small
@@ -1044,7 +1054,10 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(RT
 #if RT_LANE_STATS == 1
             if (COUNT) slots++;
 #endif
-            if (at_inner) cur = node_step<COUNT, SMALL_TREE>(src, r, cur, tmax, st, pr);
+            if (at_inner) {
+                cur = node_step<COUNT, SMALL_TREE>(src, r, cur, tmax, st, pr);
+                if (COUNT) pr.max_sp = max(pr.max_sp, (uint32_t)st.sp);
+            }
         }
         // sphere and quad leaves
         {
@@ -1482,6 +1495,49 @@ __global__ __launch_bounds__(256) void k_intersect(DScene sc, uint64_t seed, con
     }
 }
 
+// The render path's traversal on caller-supplied rays (per-ray parity checks of k_extend): rays enter the queue
+// layout here, k_first_leaves / k_extend run on the queue as they do in a render, and the hit records are
+// completed afterwards.  A ray's path id is (rng_sample << pixel_bits) | rng_pixel, so the medium draws get the
+// (pixel, sample) key the caller gave.
+__global__ __launch_bounds__(256) void k_pack_rays(const rt_ray* __restrict__ rays, unsigned long long n, uint32_t pixel_bits,
+                                                   float4* __restrict__ ray_o, float4* __restrict__ ray_d) {
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const rt_ray r = rays[i];
+        const uint32_t id = (r.rng_sample << pixel_bits) | r.rng_pixel;
+        ray_o[i] = make_float4(r.origin[0], r.origin[1], r.origin[2], r.time);
+        ray_d[i] = make_float4(r.direction[0], r.direction[1], r.direction[2], __uint_as_float(id));
+    }
+}
+
+RT_D rt_hit hit_record_of(const DScene& sc, uint32_t ref, float3 o, float3 d, float time, float t) {
+    rt_hit h = rt_hit{};
+    if (ref != REF_NONE) {
+        HitGeom g = resolve_hit(sc, ref, leaf_meta(sc, ref)[0], o, d, time, t);
+        ensure_uv(g);
+        h.t = t;
+        h.point[0] = g.p.x; h.point[1] = g.p.y; h.point[2] = g.p.z;
+        h.normal[0] = g.normal.x; h.normal[1] = g.normal.y; h.normal[2] = g.normal.z;
+        h.u = g.u; h.v = g.v;
+        h.prim_id = g.prim_id;
+        h.material = g.material;
+        h.front_face = g.front_face ? 1u : 0u;
+        h.hit = 1u;
+    }
+    return h;
+}
+
+__global__ __launch_bounds__(256) void k_unpack_hits(DScene sc, const rt_ray* __restrict__ rays, const uint2* __restrict__ hits,
+                                                     unsigned long long n, rt_hit* __restrict__ out) {
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const rt_ray r = rays[i];
+        const uint2 h = hits[i];
+        out[i] = hit_record_of(sc, h.y, f3(r.origin[0], r.origin[1], r.origin[2]), f3(r.direction[0], r.direction[1], r.direction[2]), r.time,
+                               __uint_as_float(h.x));
+    }
+}
+
 // Material::emitted/scatter on caller-supplied (ray, hit) pairs: per-material parity checks.
 __global__ __launch_bounds__(256) void k_shade_records(DScene sc, uint64_t seed, const rt_ray* __restrict__ rays,
                                                        const rt_hit* __restrict__ hits, unsigned long long n,
@@ -1558,6 +1614,9 @@ int extend_blocks_per_cu(bool counting) {
     int by_lds = (int)((160u * 1024u - 1024u) / (2048u * (uint32_t)RT_EXTEND_STACK + 16u));  // 2 KiB per stack level and block
     return std::min(a, by_lds);
 }
+int extend_lds_stack_levels(uint32_t n_nodes) {
+    return n_nodes <= (uint32_t)SMALL_TREE_NODES ? ExtendLds<true>::STACK_LEVELS : ExtendLds<false>::STACK_LEVELS;
+}
 // bytes of the extend kernel's stack overflow area for a grid of `blocks` blocks
 size_t extend_overflow_bytes(uint32_t blocks) { return (size_t)blocks * (EXTEND_BLOCK / 64) * OVERFLOW_STACK * 64 * sizeof(unsigned long long); }
 
@@ -1604,6 +1663,16 @@ void launch_finalize(hipStream_t st, uint32_t max_blocks, const float4* acc, uns
 void launch_intersect(hipStream_t st, uint32_t max_blocks, const DScene& sc, uint64_t seed, const rt_ray* rays, unsigned long long n,
                       rt_hit* out) {
     hipLaunchKernelGGL(k_intersect, dim3(grid_for(n, max_blocks)), dim3(256), 0, st, sc, seed, rays, n, out);
+}
+
+void launch_pack_rays(hipStream_t st, uint32_t max_blocks, const rt_ray* rays, unsigned long long n, uint32_t pixel_bits, float4* ray_o,
+                      float4* ray_d) {
+    hipLaunchKernelGGL(k_pack_rays, dim3(grid_for(n, max_blocks)), dim3(256), 0, st, rays, n, pixel_bits, ray_o, ray_d);
+}
+
+void launch_unpack_hits(hipStream_t st, uint32_t max_blocks, const DScene& sc, const rt_ray* rays, const uint2* hits, unsigned long long n,
+                        rt_hit* out) {
+    hipLaunchKernelGGL(k_unpack_hits, dim3(grid_for(n, max_blocks)), dim3(256), 0, st, sc, rays, hits, n, out);
 }
 
 void launch_shade_records(hipStream_t st, uint32_t max_blocks, const DScene& sc, uint64_t seed, const rt_ray* rays,

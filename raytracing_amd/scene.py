@@ -299,6 +299,13 @@ class Scene(BuilderCalls):
         self._check(self.amd.rt_intersect_batch(self.rt_scene, rays.ctypes.data, len(rays), seed, out.ctypes.data))
         return out
 
+    def extend(self, rays, seed=0):
+        """The same closest hits as `intersect`, computed by the render path's own traversal kernels."""
+        rays = np.ascontiguousarray(rays, dtype=_abi.ray_dtype())
+        out = np.zeros(len(rays), _abi.hit_dtype())
+        self._check(self.amd.rt_extend_batch(self.rt_scene, rays.ctypes.data, len(rays), seed, out.ctypes.data))
+        return out
+
     def shade(self, rays, hits, seed=0):
         rays = np.ascontiguousarray(rays, dtype=_abi.ray_dtype())
         hits = np.ascontiguousarray(hits, dtype=_abi.hit_dtype())

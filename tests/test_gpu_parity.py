@@ -231,7 +231,12 @@ def test_random_scene_through_the_builder_api(scene_seed):
     # Chains of Move/RotateY deeper than the reference's Move{RotateY{..}} are composed into one
     # placement, which rounds differently from applying them one by one; on grazing hits of small
     # spheres that shows up in the normal ((p - c) / r amplifies it), hence the wider bound here.
-    check_hits(gpu.intersect(rays, seed=99), cpu.intersect(rays, seed=99), normal_tol=2e-3)
+    want = cpu.intersect(rays, seed=99)
+    check_hits(gpu.intersect(rays, seed=99), want, normal_tol=2e-3)
+    # the render path's traversal kernels on the same rays (eight bounce numbers: eight launches)
+    ext = gpu.extend(rays, seed=99)
+    check_hits(ext, want, normal_tol=2e-3)
+    _same_records(ext, gpu.intersect(rays, seed=99))
     # camera with defocus blur: the disk draws come before the time draw (src/camera.rs:311-320)
     pix = np.arange(40 * 30, dtype=np.uint32)
     assert gpu.primary_rays(pix, 2, seed=5).tobytes() == cpu.primary_rays(pix, 2, seed=5).tobytes()
@@ -406,8 +411,11 @@ def test_bvh_stress_scene_against_oracle():
     # spheres of radius ~0.2 seen from ~2000 units away are below f32 resolution: whether such a
     # sphere is reported depends on the last bit of its discriminant, and the GPU agrees with the
     # oracle because both test the same boxes with the same arithmetic
-    exact = check_hits(s.intersect(rays), o.intersect(rays), min_agree=0.9995)
+    want = o.intersect(rays)
+    exact = check_hits(s.intersect(rays), want, min_agree=0.9995)
     assert exact >= 0.9995
+    assert check_hits(s.extend(rays), want, min_agree=0.9995) >= 0.9995
+    _same_records(s.extend(rays), s.intersect(rays))
     s.render_samples(2)
     assert np.allclose(s.accumulator(), o.render(2), rtol=1e-5, atol=1e-6)
 
@@ -434,3 +442,90 @@ def test_headline_size_properties():
     only2 = np.zeros((2160, 3840, 4), np.float32)
     u.render_accumulate_host(only2, first_sample=2, n_samples=1, seed=1)
     assert np.array_equal(first[..., :3] + only2[..., :3], two[..., :3])
+
+
+# ---- the render path's own traversal kernels, ray by ray (rt_extend_batch) ---------------------------------
+
+def _same_records(a, b):
+    """Hit records equal field by field (NaN u, v from acos of a hair above 1 count as equal)."""
+    for f in a.dtype.names:
+        if f != "_pad":
+            assert np.array_equal(a[f], b[f], equal_nan=a[f].dtype.kind == "f"), f
+
+
+@pytest.mark.parametrize("sid", GOLDEN_SCENES)
+def test_extend_kernel_matches_golden_and_intersect(sid):
+    """k_first_leaves + k_extend (persistent waves, LDS stack, the tree in LDS for the small scenes) on the golden
+    camera rays and on the golden scattered rays: against the oracle's records to the per-ray tolerance, and
+    against the one-thread-per-ray kernel bit for bit (media included: both key the free-path draw alike)."""
+    g, w, h, depth, spp, seed = golden(sid)
+    scene = rt.Scene.builtin(sid, w, h, max_depth=depth)
+    for rays, hits in ((g["rays"], g["hits"]), (g["rays2"], g["hits2"])):
+        got = scene.extend(rays, seed=seed)
+        exact = check_hits(got, hits)
+        assert exact == 1.0 or sid in (1, 7, 8)
+        _same_records(got, scene.intersect(rays, seed=seed))
+
+
+def _shells(s, n):
+    """n concentric spheres, radii growing by a quarter each: from the common centre a ray is inside every box, so
+    nothing on the traversal stack is ever dropped and the stack gets as deep as the tree allows."""
+    mats = [s.lambertian(s.tex_solid(0.2 + 0.01 * i, 0.5, 0.5)) for i in range(4)]
+    s.set_world(s.bvh([s.sphere((0, 0, 0), float(1.25 ** i), mats[i % 4]) for i in range(n)]))
+    s.camera((0, 0, 0), 32, 32, max_depth=4, vfov=90.0, background=(1, 1, 1), yaw=90.0)
+    return s
+
+
+def _overlapping_cluster(s, n, rng):
+    mats = [s.lambertian(s.tex_solid(*rng.uniform(0.1, 0.9, 3))) for _ in range(4)]
+    items = [s.sphere(rng.uniform(-1, 1, 3), float(rng.uniform(5, 6)), mats[i % 4]) for i in range(n)]
+    s.set_world(s.bvh(items))
+    s.camera((0, 0, 0), 32, 32, max_depth=4, vfov=90.0, background=(1, 1, 1), yaw=90.0)
+    return s
+
+
+@pytest.mark.parametrize("kind", ["shells_small_tree", "cluster_large_tree"])
+def test_extend_kernel_stack_overflow_area(kind):
+    """Trees whose traversal needs more stack levels than k_extend keeps in LDS (8 next to the LDS copy of a small
+    tree, 12 otherwise): the deeper levels live in the global overflow area.  The work counters report the deepest
+    stack any ray had, which must be beyond the LDS levels; the hits must still be the oracle's."""
+    if kind == "shells_small_tree":
+        gpu, cpu, lds_levels = _shells(rt.Scene(), 40), _shells(ob.OracleScene(), 40), 8
+    else:
+        gpu = _overlapping_cluster(rt.Scene(), 1024, np.random.default_rng(5))
+        cpu, lds_levels = _overlapping_cluster(ob.OracleScene(), 1024, np.random.default_rng(5)), 12
+    rng = np.random.default_rng(11)
+    n = 4096
+    rays = np.zeros(n, _abi.ray_dtype())
+    rays["origin"] = rng.uniform(-0.2, 0.2, (n, 3))
+    rays["direction"] = rng.normal(size=(n, 3))
+    rays["time"] = rng.uniform(0, 1, n)
+    rays["tmin"], rays["tmax"] = 0.001, np.inf
+    rays["rng_pixel"], rays["rng_sample"] = np.arange(n), 1
+    info = gpu.info()
+    assert (info["bvh_nodes"] <= 64) == (kind == "shells_small_tree")
+    gpu.set_counters(True)
+    got = gpu.extend(rays)
+    c = gpu.counters(reset=True)
+    gpu.set_counters(False)
+    assert c["max_stack"] > lds_levels, c
+    assert check_hits(got, cpu.intersect(rays)) == 1.0
+    _same_records(got, gpu.intersect(rays))
+    _same_records(got, gpu.extend(rays))   # and without the counting build
+    # the same trees through a whole render (raygen -> extend -> shade), shared random numbers
+    gpu.set_seed(2)
+    gpu.render_samples(2)
+    assert np.allclose(gpu.accumulator(), cpu.render(2, seed=2), rtol=1e-5, atol=1e-6)
+
+
+def test_extend_kernel_rejects_rays_the_render_path_never_casts():
+    s = rt.Scene.builtin(6, 16, 16)
+    rays = s.primary_rays(np.arange(4, dtype=np.uint32), 1)
+    rays["tmax"][2] = 5.0
+    with pytest.raises(rt.RenderError, match="0.001"):
+        s.extend(rays)
+    rays = s.primary_rays(np.arange(4, dtype=np.uint32), 1)
+    rays["rng_pixel"][1], rays["rng_sample"][3] = 1 << 20, 1 << 20
+    with pytest.raises(rt.RenderError, match="32"):
+        s.extend(rays)
+    assert s.extend(np.zeros(0, _abi.ray_dtype())).shape == (0,)
