@@ -373,6 +373,30 @@ int rt_render_accumulate_rows_device(rt_scene* scene, const rt_camera_desc* cam,
                                      uint32_t n_samples, uint32_t first_row,
                                      uint32_t n_rows, float* d_acc);
 
+/* rt_render_accumulate_device for callers that cannot allocate.  It has no
+ * counterpart in the reference; it is for callers that must not reach
+ * hipMalloc / hipFree: code under HIP graph capture, tight serving loops
+ * (one sample per frame of an interactive view), harnesses that forbid
+ * allocation.  Same arguments, same result bit for bit; the difference is
+ * where the ray queues live: in a fixed array that is part of the library's
+ * device image (about 57 MiB per GPU the library runs on, held until the
+ * process ends) instead of memory the context allocates on demand.  The array
+ * holds one batch of 262144 paths (larger jobs are cut into batches of that
+ * size: more launches, same image), queue counters for max_depth <= 1024
+ * (RT_ERR_UNSUPPORTED beyond it) and a traversal-stack overflow area for 256
+ * blocks of the extend kernel (trees deep enough to need that area run on that
+ * smaller grid).  The call allocates nothing: no device or host memory, no
+ * stream, no event; per-launch phase timing is ignored by it, and the work
+ * counters - a blocking read-back - should be off.  All calls on one GPU share
+ * that GPU's array: two of them that overlap in time (other contexts, other
+ * streams) race; calls on one stream are ordered and safe.  The context must
+ * have been created before graph capture starts (rt_ctx_create looks up the
+ * array's address).  Enqueues on the context's stream. */
+int rt_render_accumulate_device_noalloc(rt_scene* scene,
+                                        const rt_camera_desc* cam,
+                                        uint64_t seed, uint32_t first_sample,
+                                        uint32_t n_samples, float* d_acc);
+
 /* Replaces the per-pixel closures of Camera::hdr_render / realtime_render
  * (src/camera.rs:95-100,115-118) and Colour::to_rgba (src/math/vec3.rs:252-259).
  * d_acc: n_pixels*4 floats.  d_out: n_pixels*4 floats (modes 0, 1) or

@@ -117,6 +117,7 @@ RT_ABI = {
     "rt_render_accumulate": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_render_accumulate_device": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_render_accumulate_rows_device": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _U32, _U32, _P]),
+    "rt_render_accumulate_device_noalloc": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_finalize_device": (C.c_int, [_P, _P, _U64, _U32, C.c_int, _F, _P]),
     "rt_finalize": (C.c_int, [_P, _P, _U64, _U32, C.c_int, _F, _P]),
     "rt_intersect_batch": (C.c_int, [_P, _P, C.c_size_t, _U64, _P]),

@@ -52,6 +52,7 @@ struct EventPair {
 };
 
 constexpr int MAX_PIPES = 2;
+constexpr int MAX_DEVICES = 64;
 constexpr uint64_t BYTES_PER_PATH = 4 * sizeof(float4) + 2 * 3 * sizeof(float) + sizeof(uint2) + sizeof(uint32_t) + sizeof(float4);
 
 // Everything one batch in flight needs: the ray / throughput queues (double-buffered), hit
@@ -71,6 +72,27 @@ struct Pipe {
     unsigned long long* stack_overflow = nullptr;
     hipEvent_t done = nullptr;     // accumulate of the pipe's latest batch
 };
+
+// ---- scratch memory of rt_render_accumulate_device_noalloc ------------------------------------------
+// One pipeline's queues for NOALLOC_PATHS paths, its queue counters for up to NOALLOC_MAX_DEPTH bounces and a
+// stack overflow area for NOALLOC_OVERFLOW_BLOCKS blocks of the extend kernel, carved out of one array that is
+// part of the library's device image: every GPU the library is loaded on holds its own copy for the life of the
+// process.  Host code never uses the array's name as an address: rt_ctx_create asks the runtime for the array's
+// device address on the context's GPU (scratch_base, per device) and everything else goes through that pointer.
+constexpr uint64_t NOALLOC_PATHS = 1ull << 18;
+constexpr uint32_t NOALLOC_MAX_DEPTH = 1024;
+constexpr uint32_t NOALLOC_OVERFLOW_BLOCKS = 256;
+constexpr size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+constexpr size_t NOALLOC_RAY_BYTES = align256(NOALLOC_PATHS * sizeof(float4));
+constexpr size_t NOALLOC_THR_BYTES = align256(NOALLOC_PATHS * 3 * sizeof(float));
+constexpr size_t NOALLOC_HITS_BYTES = align256(NOALLOC_PATHS * sizeof(uint2));
+constexpr size_t NOALLOC_TEX_BYTES = align256(NOALLOC_PATHS * sizeof(uint32_t));
+constexpr size_t NOALLOC_COUNTS_BYTES = align256((2 * NOALLOC_MAX_DEPTH + 2) * sizeof(uint32_t));
+constexpr size_t NOALLOC_OVERFLOW_BYTES = (size_t)NOALLOC_OVERFLOW_BLOCKS * 4 * (rt::TRAVERSAL_STACK_ENTRIES - 8) * 64 * sizeof(unsigned long long);
+constexpr size_t NOALLOC_SCRATCH_BYTES = 5 * NOALLOC_RAY_BYTES /* ray_o x2, ray_d x2, radiance */ + 2 * NOALLOC_THR_BYTES + NOALLOC_HITS_BYTES +
+                                         NOALLOC_TEX_BYTES + NOALLOC_COUNTS_BYTES + NOALLOC_OVERFLOW_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+unsigned char* scratch_base[MAX_DEVICES] = {};  // device address of `scratch` on each GPU a context was created on
 
 }  // namespace
 
@@ -173,9 +195,9 @@ void destroy_pipe(Pipe& p) {
 }
 
 // ---- per-launch phase timing ------------------------------------------------------
-int phase_begin(rt_ctx* c, hipStream_t stream, int phase, EventPair** out) {
+int phase_begin(rt_ctx* c, bool timing, hipStream_t stream, int phase, EventPair** out) {
     *out = nullptr;
-    if (!c->phase_timing) return RT_OK;
+    if (!timing) return RT_OK;
     if (c->ev_used == c->ev_pool.size()) {
         EventPair p{};
         HIP_TRY(hipEventCreate(&p.a));
@@ -423,7 +445,14 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         if (getenv("RT_AMD_VERBOSE"))
             fprintf(stderr, "[rt_amd] extend kernel: %d blocks per CU, grid %u; %d pipeline(s)\n", per_cu, c->extend_blocks, c->n_pipes);
     }
-    hipError_t e = hipMalloc((void**)&c->d_counters, sizeof(DCounters));
+    hipError_t e = hipSuccess;
+    if (device_id < MAX_DEVICES && scratch_base[device_id] == nullptr) {
+        // this GPU's copy of the scratch array (the device is current): its address, once per device
+        void* at = nullptr;
+        e = hipGetSymbolAddress(&at, HIP_SYMBOL(scratch));
+        if (e == hipSuccess) scratch_base[device_id] = (unsigned char*)at;
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(DCounters));
     if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(DCounters));
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
@@ -1005,8 +1034,11 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
     return rt_render_accumulate_rows_device(sc, cam, seed, first_sample, n_samples, 0, cam->height, d_acc);
 }
 
-int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, uint32_t first_sample, uint32_t n_samples,
-                                     uint32_t first_row, uint32_t n_rows, float* d_acc) {
+// The host side of the wavefront loop.  fixed == nullptr: the context's pipelines, their queues (re)allocated as the
+// job needs.  fixed != nullptr: that one pipeline, whose queues the caller has put into memory that exists already;
+// nothing is allocated on this path (no queue growth, no new stream or event, no per-launch timing events).
+static int render_rows(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, uint32_t first_sample, uint32_t n_samples,
+                       uint32_t first_row, uint32_t n_rows, float* d_acc, Pipe* fixed) {
     if (!sc || !d_acc) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
     int e = check_camera(cam);
     if (e) return e;
@@ -1019,10 +1051,13 @@ int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, ui
     const uint64_t npix = (uint64_t)cam->width * n_rows;
     const uint64_t all_paths = npix * (uint64_t)n_samples;
     // one pipeline for small jobs (and for single-sample calls, which are not split)
-    const int n_pipes = (c->n_pipes > 1 && n_samples >= 2 && all_paths >= (1ull << 22)) ? c->n_pipes : 1;
+    const int n_pipes = (!fixed && c->n_pipes > 1 && n_samples >= 2 && all_paths >= (1ull << 22)) ? c->n_pipes : 1;
+    Pipe* pipes[MAX_PIPES];
+    for (int i = 0; i < MAX_PIPES; ++i) pipes[i] = fixed ? fixed : &c->pipes[i];
+    const bool timing = c->phase_timing && !fixed;
     // paths per batch: the configured number, but no more than fits the memory that is free now
-    uint64_t batch_paths = c->batch_paths;
-    {
+    uint64_t batch_paths = fixed ? fixed->cap : c->batch_paths;
+    if (!fixed) {
         uint64_t have = 0;
         for (int i = 0; i < n_pipes; ++i) have += c->pipes[i].cap;
         const uint64_t wanted = std::min<uint64_t>(batch_paths * n_pipes, all_paths);
@@ -1042,8 +1077,15 @@ int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, ui
     // counts[0 .. max_depth + 1]: queue lengths per bounce; counts[max_depth + 2 + bounce]: textured hits of that bounce
     const uint32_t n_queue_counts = cam->max_depth + 2;
     const uint32_t n_counts = 2 * cam->max_depth + 2;
-    for (int i = 0; i < n_pipes; ++i)
-        if ((e = ensure_queues(c, c->pipes[i], (uint64_t)chunk_pixels * spb, n_counts, needs_overflow(sc)))) return e;
+    if (fixed) {
+        if (n_counts > fixed->counts_cap) return fail(RT_ERR_UNSUPPORTED, "max_depth %u is beyond what the preallocated queue counters hold", cam->max_depth);
+    } else {
+        for (int i = 0; i < n_pipes; ++i)
+            if ((e = ensure_queues(c, c->pipes[i], (uint64_t)chunk_pixels * spb, n_counts, needs_overflow(sc)))) return e;
+    }
+    // persistent grid of the extend kernel; a preallocated overflow area bounds it for the trees that use that area
+    uint32_t extend_grid = c->counters_on ? c->extend_blocks_counting : c->extend_blocks;
+    if (fixed && needs_overflow(sc)) extend_grid = std::min(extend_grid, NOALLOC_OVERFLOW_BLOCKS);
     DCamera dcam = to_dcamera(cam);
     DCounters* counters = c->counters_on ? c->d_counters : nullptr;
     rt::ExtendTuning tune = c->tune;
@@ -1051,7 +1093,7 @@ int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, ui
 
     HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
     if (n_pipes > 1)
-        for (int i = 0; i < n_pipes; ++i) HIP_TRY(hipStreamWaitEvent(c->pipes[i].stream, c->ev_begin, 0));
+        for (int i = 0; i < n_pipes; ++i) HIP_TRY(hipStreamWaitEvent(pipes[i]->stream, c->ev_begin, 0));
     uint32_t batch_no = 0;
     Pipe* prev = nullptr;
     // all launches of the call; whatever it returns, the pipelines' streams are joined to the caller's afterwards
@@ -1062,10 +1104,10 @@ int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, ui
                 const uint32_t ns = std::min(spb, n_samples - s0);
                 const BatchInfo b = rt::make_batch((uint32_t)(pix0 + p0), np, first_sample + s0, ns);
                 const uint32_t total = np * ns;
-                Pipe& q = c->pipes[batch_no % (uint32_t)n_pipes];
+                Pipe& q = *pipes[batch_no % (uint32_t)n_pipes];
                 hipStream_t st = n_pipes > 1 ? q.stream : c->stream;
                 EventPair* ep;
-                if ((e = phase_begin(c, st, 0, &ep))) return e;
+                if ((e = phase_begin(c, timing, st, 0, &ep))) return e;
                 // leaves kept out of the tree: tested by ray generation for the camera rays (by the counting pass when
                 // the work counters are on), by a pass of their own for the rays shade creates
                 const bool raygen_first_leaves = sc->d.n_global != 0 && counters == nullptr;
@@ -1075,15 +1117,15 @@ int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, ui
                 int cur = 0;
                 for (uint32_t bounce = 0; bounce < cam->max_depth; ++bounce) {
                     if (sc->d.n_global != 0 && !(bounce == 0 && raygen_first_leaves)) {
-                        if ((e = phase_begin(c, st, 4, &ep))) return e;
+                        if ((e = phase_begin(c, timing, st, 4, &ep))) return e;
                         launch_first_leaves(st, c->max_blocks, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur], q.ray_d[cur], q.hits, counters);
                         if ((e = phase_end(st, ep))) return e;
                     }
-                    if ((e = phase_begin(c, st, 1, &ep))) return e;
-                    launch_extend(st, counters ? c->extend_blocks_counting : c->extend_blocks, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur],
+                    if ((e = phase_begin(c, timing, st, 1, &ep))) return e;
+                    launch_extend(st, extend_grid, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur],
                                   q.ray_d[cur], q.hits, q.stack_overflow, tune, counters);
                     if ((e = phase_end(st, ep))) return e;
-                    if ((e = phase_begin(c, st, 2, &ep))) return e;
+                    if ((e = phase_begin(c, timing, st, 2, &ep))) return e;
                     launch_shade(st, c->max_blocks, total, sc->d, dcam, b, seed, bounce, q.counts, q.counts + n_queue_counts + bounce, q.tex_list,
                                  q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.hits, q.ray_o[cur ^ 1], q.ray_d[cur ^ 1], q.thr[cur ^ 1], q.radiance,
                                  sc->has_textures);
@@ -1094,7 +1136,7 @@ int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, ui
                 // the accumulation buffer takes the batches in their order: sample sums stay bit-identical
                 // to a one-pipeline render
                 if (n_pipes > 1 && prev && prev != &q) HIP_TRY(hipStreamWaitEvent(st, prev->done, 0));
-                if ((e = phase_begin(c, st, 3, &ep))) return e;
+                if ((e = phase_begin(c, timing, st, 3, &ep))) return e;
                 launch_accumulate(st, c->max_blocks, b, q.radiance, (float4*)d_acc);
                 if ((e = phase_end(st, ep))) return e;
                 if (n_pipes > 1) HIP_TRY(hipEventRecord(q.done, st));
@@ -1106,14 +1148,14 @@ int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, ui
     const int enqueued = enqueue();
     if (n_pipes > 1) {
         if (enqueued != RT_OK)  // a batch was cut short: its pipeline's stream still has to be waited for
-            for (int i = 0; i < n_pipes; ++i) (void)hipEventRecord(c->pipes[i].done, c->pipes[i].stream);
-        for (int i = 0; i < n_pipes && (enqueued != RT_OK || i < (int)batch_no); ++i) HIP_TRY(hipStreamWaitEvent(c->stream, c->pipes[i].done, 0));
+            for (int i = 0; i < n_pipes; ++i) (void)hipEventRecord(pipes[i]->done, pipes[i]->stream);
+        for (int i = 0; i < n_pipes && (enqueued != RT_OK || i < (int)batch_no); ++i) HIP_TRY(hipStreamWaitEvent(c->stream, pipes[i]->done, 0));
     }
     if (enqueued != RT_OK) return enqueued;
     HIP_TRY(hipEventRecord(c->ev_end, c->stream));
     HIP_TRY(hipGetLastError());
     c->have_render_time = true;
-    c->phase_pending = c->phase_pending || c->phase_timing;
+    c->phase_pending = c->phase_pending || timing;
     if (c->counters_on) {
         // paths started: one per (pixel, sample)
         unsigned long long add = npix * n_samples;
@@ -1124,6 +1166,41 @@ int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, ui
         HIP_TRY(hipMemcpy(c->d_counters, &h, sizeof(h), hipMemcpyHostToDevice));
     }
     return RT_OK;
+}
+
+int rt_render_accumulate_rows_device(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, uint32_t first_sample, uint32_t n_samples,
+                                     uint32_t first_row, uint32_t n_rows, float* d_acc) {
+    return render_rows(sc, cam, seed, first_sample, n_samples, first_row, n_rows, d_acc, nullptr);
+}
+
+int rt_render_accumulate_device_noalloc(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, uint32_t first_sample, uint32_t n_samples,
+                                        float* d_acc) {
+    if (!sc || !cam || !d_acc) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    rt_ctx* c = sc->ctx;
+    if (cam->max_depth > NOALLOC_MAX_DEPTH)
+        return fail(RT_ERR_UNSUPPORTED, "max_depth %u: this entry point's preallocated queue counters hold at most %u bounces", cam->max_depth,
+                    NOALLOC_MAX_DEPTH);
+    unsigned char* base = c->device < MAX_DEVICES ? scratch_base[c->device] : nullptr;
+    if (!base) return fail(RT_ERR_UNSUPPORTED, "no preallocated scratch memory on device %d", c->device);
+    if (rt::extend_overflow_bytes(NOALLOC_OVERFLOW_BLOCKS) > NOALLOC_OVERFLOW_BYTES) return fail(RT_ERR_HIP, "internal error: overflow area too small");
+    // one pipeline on the caller's stream, its queues laid out in the scratch array of this GPU
+    Pipe q;
+    unsigned char* at = base;
+    auto take = [&](size_t bytes) { unsigned char* p = at; at += bytes; return p; };
+    for (int i = 0; i < 2; ++i) {
+        q.ray_o[i] = (float4*)take(NOALLOC_RAY_BYTES);
+        q.ray_d[i] = (float4*)take(NOALLOC_RAY_BYTES);
+        q.thr[i] = (float*)take(NOALLOC_THR_BYTES);
+    }
+    q.radiance = (float4*)take(NOALLOC_RAY_BYTES);
+    q.hits = (uint2*)take(NOALLOC_HITS_BYTES);
+    q.tex_list = (uint32_t*)take(NOALLOC_TEX_BYTES);
+    q.counts = (uint32_t*)take(NOALLOC_COUNTS_BYTES);
+    q.counts_cap = 2 * NOALLOC_MAX_DEPTH + 2;
+    q.stack_overflow = (unsigned long long*)take(NOALLOC_OVERFLOW_BYTES);
+    q.cap = NOALLOC_PATHS;
+    if ((size_t)(at - base) != NOALLOC_SCRATCH_BYTES) return fail(RT_ERR_HIP, "internal error: scratch layout");
+    return render_rows(sc, cam, seed, first_sample, n_samples, 0, cam->height, d_acc, &q);
 }
 
 int rt_render_accumulate(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, uint32_t first_sample, uint32_t n_samples,

@@ -335,6 +335,11 @@ class Scene(BuilderCalls):
         cam = self.camera_desc()
         self._check(self.amd.rt_render_accumulate_device(self.rt_scene, C.byref(cam), seed, first_sample, n_samples, d_acc))
 
+    def render_accumulate_device_noalloc(self, d_acc, first_sample, n_samples, seed=0):
+        """The variant that allocates nothing: its queues live in the library's fixed device array."""
+        cam = self.camera_desc()
+        self._check(self.amd.rt_render_accumulate_device_noalloc(self.rt_scene, C.byref(cam), seed, first_sample, n_samples, d_acc))
+
     def render_accumulate_rows_device(self, d_acc, first_sample, n_samples, first_row, n_rows, seed=0):
         """Rows first_row .. first_row + n_rows - 1 only; d_acc is still the whole-image buffer."""
         cam = self.camera_desc()
