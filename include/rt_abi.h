@@ -293,6 +293,16 @@ int rt_ctx_set_batch_paths(rt_ctx* ctx, uint64_t max_paths);
  * buffer takes the batches in sample order either way, so results are
  * bit-identical.  Queue memory is held per pipeline. */
 int rt_ctx_set_pipelines(rt_ctx* ctx, int n);
+/* How the bounces of a batch are scheduled (no effect on the image, which is
+ * bit-identical either way).  Bounces below first_bounce run as one pass of
+ * the per-bounce kernels each (first leaves, extend, shade over the compacted
+ * queue); from first_bounce on, one launch of the tail kernel takes every
+ * surviving path to its end (one thread per path, the loop of ray_colour,
+ * src/camera.rs:339-364).  -1 (default): chosen per batch from its size -
+ * small batches (interactive frames, low-resolution renders) switch after a
+ * few bounces, batches above 2^24 paths never.  0: whole paths in the tail
+ * kernel.  Any value >= max_depth: per-bounce kernels only. */
+int rt_ctx_set_tail_start(rt_ctx* ctx, int first_bounce);
 /* Turn the work counters on or off (off by default: they cost atomics). */
 int rt_ctx_set_counters(rt_ctx* ctx, int enabled);
 int rt_ctx_get_counters(rt_ctx* ctx, rt_counters* out, int reset);
@@ -305,6 +315,14 @@ int rt_buffer_destroy(rt_ctx* ctx, void* d_ptr);
 int rt_buffer_zero(rt_ctx* ctx, void* d_ptr, size_t bytes);
 int rt_buffer_upload(rt_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int rt_buffer_download(rt_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+/* Page-locked host memory for the buffers that cross the bus on every call of
+ * the host-buffer entry points (a Camera's `acc_colours`, src/camera.rs:25):
+ * copies from and to it run at the link's full rate and beside kernels, which
+ * copies from ordinary (pageable) memory do not.  Ordinary memory is accepted
+ * everywhere; this is the faster choice for callers that can place the buffer. */
+int rt_host_buffer_create(rt_ctx* ctx, size_t bytes, void** out);
+int rt_host_buffer_destroy(rt_ctx* ctx, void* ptr);
 
 /* Replaces World::new + the walk a Rust caller would do over its Hittable
  * tree (src/lib.rs:17-26, src/hittable.rs:35-57): copies the description,
@@ -353,11 +371,20 @@ int rt_bvh_build_check(const float* boxes, uint32_t n, rt_bvh_report* out);
  * acc is width*height*4 floats, row-major, row 0 on top, lane 3 untouched
  * (the reference's Vec<f32x4> acc_colours, src/camera.rs:25).  Random numbers
  * are a pure function of (seed, pixel, sample, bounce), so the result does not
- * depend on batch size, scheduling or how samples are split over GPUs.
- * Blocking; acc_host is read and written on the host. */
+ * are the same whatever the batch size, the scheduling or the split of samples
+ * over GPUs: images are bit-identical across batch sizes, pipelines, row
+ * ranges and consecutive calls on one buffer, and equal up to the order of the
+ * f32 additions when per-GPU buffers of different sample ranges are summed.
+ * Blocking; acc_host is read and written on the host.  The buffer is uploaded
+ * (beside the render), accumulated into on the GPU and downloaded on every
+ * call.  The context keeps the device copy's memory and keeps the caller's
+ * buffer registered (page-locked) with the HIP runtime for as long as the same
+ * buffer keeps being passed; before freeing such a buffer call
+ * rt_ctx_release_host_buffer (or destroy the context). */
 int rt_render_accumulate(rt_scene* scene, const rt_camera_desc* cam,
                          uint64_t seed, uint32_t first_sample,
                          uint32_t n_samples, float* acc_host);
+int rt_ctx_release_host_buffer(rt_ctx* ctx);
 /* Same with the accumulation buffer resident on the GPU; enqueues on the
  * context's stream and returns without waiting. */
 int rt_render_accumulate_device(rt_scene* scene, const rt_camera_desc* cam,
@@ -456,7 +483,8 @@ int rt_ctx_synchronize(rt_ctx* ctx);
  * rt_ctx_synchronize sums them per phase over all renders enqueued since the
  * previous rt_ctx_synchronize, and rt_ctx_phase_ms reads the sums (milliseconds,
  * number of launches).  phase: 0 raygen, 1 extend, 2 shade, 3 accumulate,
- * 4 the pass over the leaves kept out of the tree (part of extend). */
+ * 4 the pass over the leaves kept out of the tree (part of extend), 5 the tail
+ * kernel. */
 int rt_ctx_last_render_ms(rt_ctx* ctx, float* total_ms);
 int rt_ctx_set_phase_timing(rt_ctx* ctx, int enabled);
 int rt_ctx_phase_ms(rt_ctx* ctx, int phase, float* ms, uint32_t* launches);

@@ -103,6 +103,7 @@ RT_ABI = {
     "rt_ctx_set_stream": (C.c_int, [_P, _P]),
     "rt_ctx_set_batch_paths": (C.c_int, [_P, _U64]),
     "rt_ctx_set_pipelines": (C.c_int, [_P, C.c_int]),
+    "rt_ctx_set_tail_start": (C.c_int, [_P, C.c_int]),
     "rt_ctx_set_counters": (C.c_int, [_P, C.c_int]),
     "rt_ctx_get_counters": (C.c_int, [_P, C.POINTER(RtCounters), C.c_int]),
     "rt_buffer_create": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
@@ -110,11 +111,14 @@ RT_ABI = {
     "rt_buffer_zero": (C.c_int, [_P, _P, C.c_size_t]),
     "rt_buffer_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "rt_buffer_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "rt_host_buffer_create": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "rt_host_buffer_destroy": (C.c_int, [_P, _P]),
     "rt_scene_create": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "rt_scene_destroy": (C.c_int, [_P]),
     "rt_scene_get_info": (C.c_int, [_P, C.POINTER(RtSceneInfo)]),
     "rt_bvh_build_check": (C.c_int, [_FP, _U32, C.POINTER(RtBvhReport)]),
     "rt_render_accumulate": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
+    "rt_ctx_release_host_buffer": (C.c_int, [_P]),
     "rt_render_accumulate_device": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_render_accumulate_rows_device": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _U32, _U32, _P]),
     "rt_render_accumulate_device_noalloc": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),

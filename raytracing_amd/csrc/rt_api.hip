@@ -44,7 +44,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr uint64_t DEFAULT_BATCH_PATHS = 128ull << 20;  // 116 B of queue memory per path
-constexpr int N_PHASES = 5;
+constexpr int N_PHASES = 6;
 
 struct EventPair {
     hipEvent_t a, b;
@@ -102,10 +102,24 @@ struct rt_ctx {
     uint32_t max_blocks = 2048;
     uint32_t extend_blocks = 1024;  // persistent grid of the extend kernel: what the chip holds at once
     uint32_t extend_blocks_counting = 1024;  // the same for its counting build (more registers)
+    uint32_t tail_blocks = 512;     // what the chip holds of the tail kernel
     rt::ExtendTuning tune;
     uint64_t batch_paths = DEFAULT_BATCH_PATHS;
     bool counters_on = false;
     bool phase_timing = false;
+    uint32_t tail_rays = 3u << 16;  // queue length at which the tail kernel should take over
+    int tail_start = -1;  // first bounce the tail kernel takes over (-1: chosen per batch, see tail_start_for)
+    // queue lengths per bounce of the latest batch, copied to pinned host memory when its call ends: what the next
+    // batch of the same job uses to place the switch to the tail kernel
+    uint32_t* h_counts = nullptr;
+    hipEvent_t ev_counts = nullptr;
+    struct {
+        const rt_scene* scene = nullptr;
+        uint32_t width = 0, height = 0, max_depth = 0, paths = 0;
+        uint32_t n = 0;           // entries of h_counts in flight or valid
+        uint32_t ran_to = 0;      // bounces the per-bounce kernels did in that batch: h_counts[0 .. ran_to] are real
+        int chosen = -1;          // the switch derived from them, once they have arrived
+    } seen;
 
     // Batches of one render call are dealt to n_pipes pipelines in turn.  With two, the kernels of
     // consecutive batches overlap on the chip: the extend kernel is bound by instruction issue
@@ -113,6 +127,15 @@ struct rt_ctx {
     int n_pipes = 2;
     Pipe pipes[MAX_PIPES];
     DCounters* d_counters = nullptr;
+
+    // host-buffer entry point: the device copy of the caller's accumulation buffer, the caller's buffer as it is
+    // registered (page-locked) with the runtime, and the stream / event of the upload that runs beside the render
+    float* d_acc_cache = nullptr;
+    size_t d_acc_cache_bytes = 0;
+    void* pinned_ptr = nullptr;
+    size_t pinned_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_upload = nullptr;
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool have_render_time = false;
@@ -387,6 +410,42 @@ int validate(const rt_scene_desc* d) {
     return RT_OK;
 }
 
+// First bounce that the tail kernel handles (everything from there to max_depth in one launch); max_depth: no tail.
+// The per-bounce kernels are the efficient way to advance a long queue and a poor way to advance a short one (every
+// bounce costs its tens of microseconds of launches and dependent round trips whatever the queue holds), while the
+// tail kernel - one thread per path, no regrouping - is the reverse: the switch belongs where the queue is down to
+// tail_rays rays.  The host does not wait for queue lengths, but a progressive render repeats the same batch with new
+// sample numbers, so the lengths of the previous batch (copied to pinned memory when its call ended) place the switch
+// of the next one; the first batch of a job uses a model that loses a quarter of the paths per bounce.  Batches above
+// 2^24 paths never get that short at the depths in use, and the counting build keeps to the kernels that count.
+constexpr uint32_t TAIL_MAX_BATCH = 1u << 24;
+constexpr uint32_t COUNTS_SEEN_MAX = 1024;
+uint32_t tail_start_for(rt_ctx* c, const rt_scene* sc, const rt_camera_desc* cam, uint64_t paths, bool learn) {
+    const uint32_t max_depth = cam->max_depth;
+    if (c->tail_start >= 0) return std::min<uint32_t>((uint32_t)c->tail_start, max_depth);
+    if (c->counters_on || paths > TAIL_MAX_BATCH) return max_depth;
+    auto& seen = c->seen;
+    if (learn && seen.scene == sc && seen.width == cam->width && seen.height == cam->height && seen.max_depth == max_depth && seen.paths == paths) {
+        if (seen.n != 0 && hipEventQuery(c->ev_counts) == hipSuccess) {
+            // first bounce whose queue was short enough; past the bounces that were counted, the last ratio continues
+            uint32_t bounce = 0;
+            while (bounce <= seen.ran_to && bounce < seen.n && c->h_counts[bounce] > c->tail_rays) ++bounce;
+            if (bounce > seen.ran_to && seen.ran_to >= 1) {
+                const double last = (double)c->h_counts[seen.ran_to], before = (double)c->h_counts[seen.ran_to - 1];
+                const double ratio = std::min(0.95, std::max(0.05, before > 0.0 ? last / before : 0.5));
+                for (double rays = last * ratio; rays > (double)c->tail_rays && bounce < max_depth; rays *= ratio) ++bounce;
+            }
+            seen.chosen = (int)std::min(bounce, max_depth);
+            seen.n = 0;  // used up; the batch about to be enqueued sends new ones
+        }
+        (void)hipGetLastError();
+        if (seen.chosen >= 0) return (uint32_t)seen.chosen;
+    }
+    uint32_t bounce = 0;
+    for (double rays = (double)paths; rays > (double)c->tail_rays && bounce < max_depth; rays *= 0.75) ++bounce;
+    return bounce;
+}
+
 bool needs_overflow(const rt_scene* sc) { return sc->stack_need > (uint32_t)rt::extend_lds_stack_levels(sc->d.n_nodes); }
 
 DCamera to_dcamera(const rt_camera_desc* c) {
@@ -411,6 +470,13 @@ int check_camera(const rt_camera_desc* cam) {
     if ((uint64_t)cam->width * cam->height >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "image larger than 2^31 pixels");
     if (cam->max_depth > 4096) return fail(RT_ERR_UNSUPPORTED, "max_depth above 4096");
     return RT_OK;
+}
+
+void release_host_buffer(rt_ctx* c) {
+    if (c->pinned_ptr) (void)hipHostUnregister(c->pinned_ptr);
+    (void)hipGetLastError();
+    c->pinned_ptr = nullptr;
+    c->pinned_bytes = 0;
 }
 
 }  // namespace
@@ -439,8 +505,10 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         if (per_cu_counting < 1) per_cu_counting = 3;
         c->extend_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)per_cu;
         c->extend_blocks_counting = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::min(per_cu, per_cu_counting);
+        c->tail_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::max(1, rt::tail_blocks_per_cu());
         if (const char* e = getenv("RT_AMD_EXTEND_TUNING"))  // "inner,refill,medium": tuning experiments only
             sscanf(e, "%d,%d,%d", &c->tune.inner_min, &c->tune.refill_min, &c->tune.medium_min);
+        if (const char* e = getenv("RT_AMD_TAIL_RAYS")) c->tail_rays = (uint32_t)std::max(1, atoi(e));  // tuning experiments only
         if (const char* e = getenv("RT_AMD_PIPES")) c->n_pipes = std::min(MAX_PIPES, std::max(1, atoi(e)));  // A/B experiments only
         if (getenv("RT_AMD_VERBOSE"))
             fprintf(stderr, "[rt_amd] extend kernel: %d blocks per CU, grid %u; %d pipeline(s)\n", per_cu, c->extend_blocks, c->n_pipes);
@@ -454,6 +522,8 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     }
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(DCounters));
     if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(DCounters));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_counts, COUNTS_SEEN_MAX * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_counts, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
     if (e != hipSuccess) {
@@ -470,6 +540,12 @@ int rt_ctx_destroy(rt_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (Pipe& p : c->pipes) destroy_pipe(p);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    release_host_buffer(c);
+    if (c->d_acc_cache) (void)hipFree(c->d_acc_cache);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->ev_counts) (void)hipEventDestroy(c->ev_counts);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -495,6 +571,12 @@ int rt_ctx_set_pipelines(rt_ctx* c, int n) {
     if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (n < 1 || n > MAX_PIPES) return fail(RT_ERR_INVALID_ARGUMENT, "%d pipelines: 1 to %d are supported", n, MAX_PIPES);
     c->n_pipes = n;
+    return RT_OK;
+}
+
+int rt_ctx_set_tail_start(rt_ctx* c, int first_bounce) {
+    if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    c->tail_start = first_bounce < 0 ? -1 : first_bounce;
     return RT_OK;
 }
 
@@ -551,6 +633,25 @@ int rt_buffer_create(rt_ctx* c, size_t bytes, void** d_out) {
     int e = set_device(c);
     if (e) return e;
     HIP_TRY(hipMalloc(d_out, std::max<size_t>(bytes, 16)));
+    return RT_OK;
+}
+
+int rt_host_buffer_create(rt_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    int e = set_device(c);
+    if (e) return e;
+    HIP_TRY(hipHostMalloc(out, std::max<size_t>(bytes, 16), hipHostMallocDefault));
+    return RT_OK;
+}
+
+int rt_host_buffer_destroy(rt_ctx* c, void* ptr) {
+    if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (!ptr) return RT_OK;
+    int e = set_device(c);
+    if (e) return e;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipHostFree(ptr));
     return RT_OK;
 }
 
@@ -1024,6 +1125,7 @@ int rt_scene_destroy(rt_scene* sc) {
     (void)hipSetDevice(sc->ctx->device);
     (void)hipStreamSynchronize(sc->ctx->stream);
     for (void* p : sc->allocations) (void)hipFree(p);
+    if (sc->ctx->seen.scene == sc) sc->ctx->seen = {};
     delete sc;
     return RT_OK;
 }
@@ -1037,8 +1139,9 @@ int rt_render_accumulate_device(rt_scene* sc, const rt_camera_desc* cam, uint64_
 // The host side of the wavefront loop.  fixed == nullptr: the context's pipelines, their queues (re)allocated as the
 // job needs.  fixed != nullptr: that one pipeline, whose queues the caller has put into memory that exists already;
 // nothing is allocated on this path (no queue growth, no new stream or event, no per-launch timing events).
+// before_accumulate: an event the accumulation kernels wait for (the buffer's contents arriving), or nullptr.
 static int render_rows(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, uint32_t first_sample, uint32_t n_samples,
-                       uint32_t first_row, uint32_t n_rows, float* d_acc, Pipe* fixed) {
+                       uint32_t first_row, uint32_t n_rows, float* d_acc, Pipe* fixed, hipEvent_t before_accumulate = nullptr) {
     if (!sc || !d_acc) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
     int e = check_camera(cam);
     if (e) return e;
@@ -1094,7 +1197,7 @@ static int render_rows(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, u
     HIP_TRY(hipEventRecord(c->ev_begin, c->stream));
     if (n_pipes > 1)
         for (int i = 0; i < n_pipes; ++i) HIP_TRY(hipStreamWaitEvent(pipes[i]->stream, c->ev_begin, 0));
-    uint32_t batch_no = 0;
+    uint32_t batch_no = 0, last_tail_start = 0, last_total = 0;
     Pipe* prev = nullptr;
     // all launches of the call; whatever it returns, the pipelines' streams are joined to the caller's afterwards
     auto enqueue = [&]() -> int {
@@ -1115,7 +1218,10 @@ static int render_rows(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, u
                               q.counts, n_counts);
                 if ((e = phase_end(st, ep))) return e;
                 int cur = 0;
-                for (uint32_t bounce = 0; bounce < cam->max_depth; ++bounce) {
+                const uint32_t tail_start = tail_start_for(c, sc, cam, total, fixed == nullptr);
+                last_tail_start = tail_start;
+                last_total = total;
+                for (uint32_t bounce = 0; bounce < tail_start; ++bounce) {
                     if (sc->d.n_global != 0 && !(bounce == 0 && raygen_first_leaves)) {
                         if ((e = phase_begin(c, timing, st, 4, &ep))) return e;
                         launch_first_leaves(st, c->max_blocks, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur], q.ray_d[cur], q.hits, counters);
@@ -1132,10 +1238,17 @@ static int render_rows(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, u
                     if ((e = phase_end(st, ep))) return e;
                     cur ^= 1;
                 }
+                if (tail_start < cam->max_depth) {
+                    if ((e = phase_begin(c, timing, st, 5, &ep))) return e;
+                    launch_tail(st, std::min(extend_grid, c->tail_blocks), total, sc->d, dcam, b, seed, tail_start, q.counts, q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.radiance,
+                                q.stack_overflow);
+                    if ((e = phase_end(st, ep))) return e;
+                }
                 if (cam->max_depth == 0) HIP_TRY(hipMemsetAsync(q.radiance, 0, (size_t)total * sizeof(float4), st));
                 // the accumulation buffer takes the batches in their order: sample sums stay bit-identical
                 // to a one-pipeline render
                 if (n_pipes > 1 && prev && prev != &q) HIP_TRY(hipStreamWaitEvent(st, prev->done, 0));
+                if (before_accumulate) HIP_TRY(hipStreamWaitEvent(st, before_accumulate, 0));
                 if ((e = phase_begin(c, timing, st, 3, &ep))) return e;
                 launch_accumulate(st, c->max_blocks, b, q.radiance, (float4*)d_acc);
                 if ((e = phase_end(st, ep))) return e;
@@ -1152,6 +1265,17 @@ static int render_rows(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, u
         for (int i = 0; i < n_pipes && (enqueued != RT_OK || i < (int)batch_no); ++i) HIP_TRY(hipStreamWaitEvent(c->stream, pipes[i]->done, 0));
     }
     if (enqueued != RT_OK) return enqueued;
+    if (!fixed && prev && c->h_counts && c->tail_start < 0 && !c->counters_on && last_total <= TAIL_MAX_BATCH && cam->max_depth >= 1) {
+        // the last batch's queue lengths, for the schedule of the next call (nobody waits for them)
+        auto& seen = c->seen;
+        const bool same = seen.scene == sc && seen.width == cam->width && seen.height == cam->height && seen.max_depth == cam->max_depth && seen.paths == last_total;
+        if (!same) seen.chosen = -1;
+        seen.scene = sc; seen.width = cam->width; seen.height = cam->height; seen.max_depth = cam->max_depth; seen.paths = last_total;
+        seen.n = std::min<uint32_t>(cam->max_depth + 1, COUNTS_SEEN_MAX);
+        seen.ran_to = std::min<uint32_t>(last_tail_start, seen.n - 1);
+        HIP_TRY(hipMemcpyAsync(c->h_counts, prev->counts, seen.n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_counts, c->stream));
+    }
     HIP_TRY(hipEventRecord(c->ev_end, c->stream));
     HIP_TRY(hipGetLastError());
     c->have_render_time = true;
@@ -1203,6 +1327,14 @@ int rt_render_accumulate_device_noalloc(rt_scene* sc, const rt_camera_desc* cam,
     return render_rows(sc, cam, seed, first_sample, n_samples, 0, cam->height, d_acc, &q);
 }
 
+int rt_ctx_release_host_buffer(rt_ctx* c) {
+    if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    int e = set_device(c);
+    if (e) return e;
+    release_host_buffer(c);
+    return RT_OK;
+}
+
 int rt_render_accumulate(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, uint32_t first_sample, uint32_t n_samples,
                          float* acc_host) {
     if (!sc || !acc_host) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1210,19 +1342,46 @@ int rt_render_accumulate(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed,
     if (e) return e;
     rt_ctx* c = sc->ctx;
     if ((e = set_device(c))) return e;
-    size_t bytes = (size_t)cam->width * cam->height * 4 * sizeof(float);
-    float* d_acc = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_acc, bytes));
-    hipError_t he = hipMemcpyAsync(d_acc, acc_host, bytes, hipMemcpyHostToDevice, c->stream);
+    const size_t bytes = (size_t)cam->width * cam->height * 4 * sizeof(float);
+    // the device copy of the buffer is kept between calls (its contents are not: the caller owns the buffer and
+    // may have changed it, so every call uploads it again)
+    if (bytes > c->d_acc_cache_bytes) {
+        if (c->d_acc_cache) (void)hipFree(c->d_acc_cache);
+        c->d_acc_cache = nullptr;
+        c->d_acc_cache_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_acc_cache, bytes));
+        c->d_acc_cache_bytes = bytes;
+    }
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->ev_upload) HIP_TRY(hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+    // The caller's buffer is page-locked once, for as long as the same buffer keeps coming (copies from and to pageable
+    // memory run at a fraction of the link's rate, and only copies from page-locked memory run beside kernels).  Not
+    // every system lets the runtime lock memory it did not allocate; rt_host_buffer_create hands out memory that is
+    // page-locked from the start, and pageable memory still works, only slower.
+    if (c->pinned_ptr != (void*)acc_host || c->pinned_bytes != bytes) {
+        release_host_buffer(c);
+        hipPointerAttribute_t attr;
+        const bool locked_already = hipPointerGetAttributes(&attr, acc_host) == hipSuccess && attr.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        if (!locked_already && hipHostRegister(acc_host, bytes, hipHostRegisterDefault) == hipSuccess) {
+            c->pinned_ptr = acc_host;
+            c->pinned_bytes = bytes;
+        }
+        (void)hipGetLastError();
+    }
+    // the upload runs beside ray generation, extend and shade; only the accumulation kernels wait for it
+    float* d_acc = c->d_acc_cache;
+    hipError_t he = hipMemcpyAsync(d_acc, acc_host, bytes, hipMemcpyHostToDevice, c->copy_stream);
+    if (he == hipSuccess) he = hipEventRecord(c->ev_upload, c->copy_stream);
     if (he == hipSuccess) {
-        e = rt_render_accumulate_device(sc, cam, seed, first_sample, n_samples, d_acc);
+        e = render_rows(sc, cam, seed, first_sample, n_samples, 0, cam->height, d_acc, nullptr, c->ev_upload);
         if (e == RT_OK) he = hipMemcpyAsync(acc_host, d_acc, bytes, hipMemcpyDeviceToHost, c->stream);
     }
+    hipError_t hc = hipStreamSynchronize(c->copy_stream);
     hipError_t hs = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_acc);
     if (e) return e;
     if (he != hipSuccess) return fail(RT_ERR_HIP, "accumulation buffer copy failed: %s", hipGetErrorString(he));
-    if (hs != hipSuccess) return fail(RT_ERR_HIP, "render failed: %s", hipGetErrorString(hs));
+    if (hs != hipSuccess || hc != hipSuccess) return fail(RT_ERR_HIP, "render failed: %s", hipGetErrorString(hs != hipSuccess ? hs : hc));
     return collect_phases(c);
 }
 

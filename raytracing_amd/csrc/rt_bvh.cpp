@@ -1,7 +1,7 @@
-// rt_bvh.cpp — binned-SAH BVH2 builder producing the 64-byte node layout of
-// rt_device.h.  One primitive per leaf; the n-1 inner nodes of an n-leaf tree
-// are preallocated and handed out through an atomic counter so that subtrees can
-// be built by several host threads.
+// rt_bvh.cpp — builder of the flattened BVH: a binary tree by binned SAH (one primitive per
+// leaf; the n-1 inner nodes of an n-leaf tree are preallocated and handed out through an
+// atomic counter so that subtrees can be built by several host threads), then folded to the
+// four-children, 128-byte node layout of rt_device.h and renumbered.
 #include "rt_bvh.h"
 
 #include <algorithm>

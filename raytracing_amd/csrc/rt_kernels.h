@@ -57,6 +57,13 @@ void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, con
                   uint64_t seed, uint32_t bounce, uint32_t* counts, uint32_t* tex_count, uint32_t* tex_list, const float4* ray_o,
                   const float4* ray_d, const float* thr, const uint2* hits, float4* out_o, float4* out_d, float* out_thr, float4* radiance,
                   bool scene_has_textures);
+// Every remaining bounce (first_bounce .. max_depth - 1) of the paths in the queue of counts[first_bounce] rays, one thread
+// per path.  resident_blocks: at most CUs x tail_blocks_per_cu() and at most the extend kernel's grid (the two kernels
+// index the stack overflow area alike).
+int tail_blocks_per_cu();
+void launch_tail(hipStream_t st, uint32_t resident_blocks, uint32_t upper_bound, const DScene& sc, const DCamera& cam, const BatchInfo& b,
+                 uint64_t seed, uint32_t first_bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, const float* thr,
+                 float4* radiance, unsigned long long* stack_overflow);
 void launch_accumulate(hipStream_t st, uint32_t max_blocks, const BatchInfo& b, const float4* radiance, float4* acc);
 void launch_finalize(hipStream_t st, uint32_t max_blocks, const float4* acc, unsigned long long n_pixels, float inv_samples, int mode,
                      float exposure, void* out);

@@ -459,6 +459,17 @@ RT_D uint2 first_leaves_hit(const DScene& sc, const BatchInfo& b, uint64_t seed,
 // Closest hit over the flattened BVH (one ray per call): returns the leaf
 // reference (REF_NONE on a miss) and its t.
 // ---------------------------------------------------------------------------
+// The tree walk of one ray from start to finish by one thread: improves (tmax, best).
+template <bool COUNT, class Stack, class Key>
+RT_D void walk_tree(const DScene& sc, const TravRay& r, float& tmax, uint32_t& best, const Key& key, Stack& st, Probe& pr) {
+    const NodeSource src{sc.nodes, nullptr, 0};
+    uint32_t cur = sc.root == REF_NONE ? REF_DONE : sc.root;
+    while (cur != REF_DONE) {
+        if (!ref_is_leaf(cur)) cur = node_step<COUNT, false>(src, r, cur, tmax, st, pr);
+        else cur = leaf_step<COUNT>(sc, r, cur, tmax, best, key, st, pr);
+    }
+}
+
 template <bool COUNT>
 RT_D uint32_t closest_hit(const DScene& sc, float3 o, float3 d, float time, float tmin, float tmax, const MediumKey& key, float& t_hit,
                           Probe& pr) {
@@ -466,12 +477,7 @@ RT_D uint32_t closest_hit(const DScene& sc, float3 o, float3 d, float time, floa
     TravRay r = make_trav_ray(o, d, time, tmin);
     global_leaves<COUNT>(sc, r, tmax, best, key, pr);
     PrivateStack st;
-    const NodeSource src{sc.nodes, nullptr, 0};
-    uint32_t cur = sc.root == REF_NONE ? REF_DONE : sc.root;
-    while (cur != REF_DONE) {
-        if (!ref_is_leaf(cur)) cur = node_step<COUNT, false>(src, r, cur, tmax, st, pr);
-        else cur = leaf_step<COUNT>(sc, r, cur, tmax, best, key, st, pr);
-    }
+    walk_tree<COUNT>(sc, r, tmax, best, key, st, pr);
     t_hit = tmax;
     return best;
 }
@@ -1123,7 +1129,9 @@ __global__ __launch_bounds__(256) void k_first_leaves(DScene sc, BatchInfo b, ui
 
 // One (ray, hit) pair through ray_colour's loop body (src/camera.rs:344-361): writes the path's
 // radiance when the path ends here, otherwise returns the next ray.
-template <bool TEXTURES>
+// TEXTURES: image / noise / nested checker textures are evaluated here (k_shade leaves those hits to k_shade_textured);
+// PLAIN_CHECKERS: a checker of two plain colours is evaluated from its per-material record.
+template <bool TEXTURES, bool PLAIN_CHECKERS = !TEXTURES>
 RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, uint64_t seed, uint32_t bounce, float4 ro, float4 rd, float4 th,
                     uint2 h, float4* __restrict__ radiance, float4& no, float4& nd, float4& nt, PerlinLds lds_perlin = PerlinLds{nullptr, nullptr, false}) {
     const uint32_t id = __float_as_uint(rd.w);  // (sample of the batch << pixel_bits) | pixel of the batch
@@ -1140,11 +1148,12 @@ RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, ui
     float3 o = f3(ro), d = f3(rd);
     HitGeom g = resolve_hit(sc, h.y, m0, o, d, ro.w, __uint_as_float(h.x));
     ShadeRec rec = shade_rec_of_leaf(sc, m0, m1);
-    if (!TEXTURES && ref_class(h.y) == CLS_CHECKER) {  // Texture::Checker over two plain colours (src/texture.rs:45-55)
+    if (PLAIN_CHECKERS && ref_class(h.y) == CLS_CHECKER) {  // Texture::Checker over two plain colours (src/texture.rs:45-55)
         const DChecker ck = sc.checkers[m0.x];
         const float sum = floorf(ck.scale * g.p.x) + floorf(ck.scale * g.p.y) + floorf(ck.scale * g.p.z);
         const bool is_even = ((int)sum % 2) == 0;
         rec.colour = is_even ? f3(ck.even[0], ck.even[1], ck.even[2]) : f3(ck.odd[0], ck.odd[1], ck.odd[2]);
+        rec.tex_kind = RT_TEX_SOLID;  // the texture has been evaluated
     }
     Rng rng;
     rng.init(path_key(seed, b.first_pixel + pixel_local, b.first_sample + s_local), bounce, STREAM_SCATTER);
@@ -1313,67 +1322,6 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
     }
 }
 
-// A/B variant of k_shade without the sort by class: every thread shades the queue slot it loads.
-__global__ __launch_bounds__(SHADE_BLOCK) void k_shade_unsorted(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce,
-                                                                uint32_t* __restrict__ counts, uint32_t* __restrict__ tex_count,
-                                                                uint32_t* __restrict__ tex_list, const float4* __restrict__ ray_o,
-                                                                const float4* __restrict__ ray_d, const float* __restrict__ thr,
-                                                                const uint2* __restrict__ hits, float4* __restrict__ out_o,
-                                                                float4* __restrict__ out_d, float* __restrict__ out_thr,
-                                                                float4* __restrict__ radiance) {
-    __shared__ float4 s_out[3][SHADE_TILE];
-    __shared__ uint32_t s_tex[SHADE_TILE];
-    __shared__ uint32_t s_alive, s_ntex, s_base, s_tex_base;
-    const uint32_t n = counts[bounce];
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    for (uint32_t tile = blockIdx.x * SHADE_TILE; tile < n; tile += gridDim.x * SHADE_TILE) {
-        if (tid == 0) { s_alive = 0; s_ntex = 0; }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < SHADE_PER_THREAD; ++k) {
-            const uint32_t i = tile + k * SHADE_BLOCK + tid;
-            bool alive = false, textured = false;
-            float4 no, nd, nt;
-            if (i < n) {
-                uint2 h = hits[i];
-                textured = h.y != REF_NONE && ref_class(h.y) == CLS_TEXTURED;
-                if (!textured) alive = shade_one<false>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], load_thr(thr, i), h, radiance, no, nd, nt);
-            }
-            unsigned long long mask = __ballot(alive), tmask = __ballot(textured);
-            if (mask) {
-                uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u, slot0 = 0;
-                if (lane == leader) slot0 = atomicAdd(&s_alive, (uint32_t)__popcll(mask));
-                slot0 = __shfl(slot0, (int)leader, 64);
-                if (alive) {
-                    uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                    s_out[0][slot] = no;
-                    s_out[1][slot] = nd;
-                    s_out[2][slot] = nt;
-                }
-            }
-            if (tmask) {
-                uint32_t leader = (uint32_t)__ffsll((long long)tmask) - 1u, slot0 = 0;
-                if (lane == leader) slot0 = atomicAdd(&s_ntex, (uint32_t)__popcll(tmask));
-                slot0 = __shfl(slot0, (int)leader, 64);
-                if (textured) s_tex[slot0 + (uint32_t)__popcll(tmask & ((1ull << lane) - 1ull))] = i;
-            }
-        }
-        __syncthreads();
-        const uint32_t n_alive = s_alive, n_tex = s_ntex;
-        if (tid == 0 && n_alive) s_base = atomicAdd(&counts[bounce + 1], n_alive);
-        if (tid == 64 && n_tex) s_tex_base = atomicAdd(tex_count, n_tex);
-        __syncthreads();
-        const uint32_t base = s_base, tbase = s_tex_base;
-        for (uint32_t j = tid; j < n_alive; j += SHADE_BLOCK) {
-            out_o[base + j] = s_out[0][j];
-            out_d[base + j] = s_out[1][j];
-            store_thr(out_thr, base + j, s_out[2][j]);
-        }
-        for (uint32_t j = tid; j < n_tex; j += SHADE_BLOCK) tex_list[tbase + j] = s_tex[j];
-        __syncthreads();
-    }
-}
-
 // The hits k_shade set aside: materials with checker, image or perlin-noise textures.  One global
 // atomic per block appends the block's survivors.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade_textured(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t bounce,
@@ -1424,6 +1372,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             store_thr(out_thr, slot, nt);
         }
         __syncthreads();
+    }
+}
+
+// Tail: every remaining bounce of the paths in a queue, in one launch.  A per-bounce pass costs tens of
+// microseconds however short its queue is (launch, one chain of dependent node fetches, one tile's chain of
+// barriers), and deep paths keep a few rays alive for dozens of bounces; once a batch is down to that regime the host
+// stops launching per-bounce kernels and this kernel takes every path of the queue to its end: one thread per path,
+// the loop of ray_colour (src/camera.rs:339-364) with the same device functions the per-bounce kernels use - the
+// leaves kept out of the tree, the tree walk (stack in LDS), the shading of all material and texture classes - and
+// the same random-number keys, so a path's radiance does not depend on where the hand-over happens.
+static constexpr int TAIL_BLOCK = 256;
+// Rays are dealt to the waves of the grid round-robin (ray i goes to wave i mod n_waves): a short queue is spread over
+// the whole chip with a few rays per wave instead of filling a few waves.  A wave takes as long as its slowest lane in
+// every part of a bounce, and runs the code of every material class its lanes have hit one after the other, so the time
+// of a bounce grows with the number of lanes in use; the kernel's time is that of its longest path, bounce after bounce.
+// A lane whose path has ended takes the wave's next ray, if there is one.
+__global__ __launch_bounds__(TAIL_BLOCK) void k_tail(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t first_bounce,
+                                                     const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
+                                                     const float4* __restrict__ ray_d, const float* __restrict__ thr,
+                                                     float4* __restrict__ radiance, unsigned long long* __restrict__ stack_overflow) {
+    __shared__ unsigned long long s_stack[TAIL_BLOCK / 64][RT_EXTEND_STACK][64];
+    const uint32_t n = counts[first_bounce];
+    const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * (TAIL_BLOCK / 64) + wave_in_block, n_waves = gridDim.x * (TAIL_BLOCK / 64);
+    if (wave >= n) return;
+    WaveStack<RT_EXTEND_STACK> st;
+    st.lds = (lds_u64*)&s_stack[wave_in_block][0][lane];
+    st.ovf = (global_u64*)(stack_overflow + ((size_t)wave * OVERFLOW_STACK) * 64 + lane);
+    Probe pr;
+    unsigned long long next = (unsigned long long)wave + (unsigned long long)lane * n_waves;  // this lane's next ray
+    const unsigned long long step = 64ull * n_waves;
+    bool have = false;
+    uint32_t bounce = first_bounce;
+    float4 ro = make_float4(0, 0, 0, 0), rd = ro, th = ro;
+    for (;;) {
+        if (!have && next < n) {
+            const uint32_t i = (uint32_t)next;
+            ro = ray_o[i]; rd = ray_d[i]; th = load_thr(thr, i);
+            bounce = first_bounce;
+            have = true;
+            next += step;
+        }
+        if (__ballot(have) == 0ull) break;  // no lane has a ray and none could fetch one
+        if (have) {
+            const BatchMediumKey key{seed, __float_as_uint(rd.w), bounce, b};
+            const TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
+            float tmax = RT_INF;
+            uint32_t best = REF_NONE;
+            global_leaves<false>(sc, r, tmax, best, key, pr);
+            st.sp = 0;
+            walk_tree<false>(sc, r, tmax, best, key, st, pr);
+            float4 no, nd, nt;
+            // (shade_one ends the path - and writes its radiance - at a miss, a light, an absorbed ray or the depth limit)
+            have = shade_one<true, true>(sc, cam, b, seed, bounce, ro, rd, th, make_uint2(__float_as_uint(tmax), best), radiance, no, nd, nt);
+            ro = no; rd = nd; th = nt;
+            ++bounce;
+        }
     }
 }
 
@@ -1614,6 +1619,12 @@ int extend_blocks_per_cu(bool counting) {
     int by_lds = (int)((160u * 1024u - 1024u) / (2048u * (uint32_t)RT_EXTEND_STACK + 16u));  // 2 KiB per stack level and block
     return std::min(a, by_lds);
 }
+int tail_blocks_per_cu() {
+    int a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_tail, TAIL_BLOCK, 0) != hipSuccess) a = 0;
+    (void)hipGetLastError();
+    return a;
+}
 int extend_lds_stack_levels(uint32_t n_nodes) {
     return n_nodes <= (uint32_t)SMALL_TREE_NODES ? ExtendLds<true>::STACK_LEVELS : ExtendLds<false>::STACK_LEVELS;
 }
@@ -1642,13 +1653,21 @@ void launch_shade(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, con
                   bool scene_has_textures) {
     unsigned long long tiles = ((unsigned long long)upper_bound + SHADE_TILE - 1) / SHADE_TILE;
     uint32_t grid = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(tiles, 1), max_blocks);
-    static const bool unsorted = getenv("RT_AMD_SHADE_UNSORTED") != nullptr;  // A/B experiment
-    auto kernel = unsorted ? k_shade_unsorted : k_shade;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(SHADE_BLOCK), 0, st, sc, cam, b, seed, bounce, counts, tex_count, tex_list, ray_o, ray_d, thr,
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(SHADE_BLOCK), 0, st, sc, cam, b, seed, bounce, counts, tex_count, tex_list, ray_o, ray_d, thr,
                        hits, out_o, out_d, out_thr, radiance);
     if (scene_has_textures)
         hipLaunchKernelGGL(k_shade_textured, dim3(grid_for(upper_bound, max_blocks)), dim3(256), 0, st, sc, cam, b, seed, bounce, counts,
                            tex_count, tex_list, ray_o, ray_d, thr, hits, out_o, out_d, out_thr, radiance);
+}
+
+void launch_tail(hipStream_t st, uint32_t resident_blocks, uint32_t upper_bound, const DScene& sc, const DCamera& cam, const BatchInfo& b,
+                 uint64_t seed, uint32_t first_bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, const float* thr,
+                 float4* radiance, unsigned long long* stack_overflow) {
+    // as many waves as the chip holds, unless there are fewer rays than that (the fewer lanes of a wave have a ray, the
+    // shorter its bounce)
+    const uint32_t blocks = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(((unsigned long long)upper_bound + 3ull) / 4ull, 1ull), resident_blocks);
+    hipLaunchKernelGGL(k_tail, dim3(blocks), dim3(TAIL_BLOCK), 0, st, sc, cam, b, seed, first_bounce, counts, ray_o,
+                       ray_d, thr, radiance, stack_overflow);
 }
 
 void launch_accumulate(hipStream_t st, uint32_t max_blocks, const BatchInfo& b, const float4* radiance, float4* acc) {

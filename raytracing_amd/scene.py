@@ -362,6 +362,10 @@ class Scene(BuilderCalls):
     def set_pipelines(self, n):
         self._check(self.amd.rt_ctx_set_pipelines(self.ctx, n))
 
+    def set_tail_start(self, first_bounce):
+        """First bounce the tail kernel takes over (-1: chosen per batch; >= max_depth: never)."""
+        self._check(self.amd.rt_ctx_set_tail_start(self.ctx, first_bounce))
+
     def set_counters(self, on):
         self._check(self.amd.rt_ctx_set_counters(self.ctx, int(on)))
 
@@ -381,7 +385,7 @@ class Scene(BuilderCalls):
     def phase_ms(self):
         """{phase: (milliseconds, launches)} of the last synchronized render."""
         out = {}
-        for i, name in enumerate(["raygen", "extend", "shade", "accumulate", "first_leaves"]):
+        for i, name in enumerate(["raygen", "extend", "shade", "accumulate", "first_leaves", "tail"]):
             ms, n = C.c_float(), C.c_uint32()
             self._check(self.amd.rt_ctx_phase_ms(self.ctx, i, C.byref(ms), C.byref(n)))
             out[name] = (ms.value, int(n.value))

@@ -6,7 +6,13 @@ import torch
 import raytracing_amd as rt
 w, h = 3840, 2160
 scene = rt.Scene.builtin(8, w, h, max_depth=25, device=0)
+import ctypes as C
 host = np.zeros((h, w, 4), np.float32)
+if os.environ.get("LOCKED", "0") == "1":   # the buffer in page-locked memory from rt_host_buffer_create
+    p = C.c_void_p()
+    scene._check(scene.amd.rt_host_buffer_create(scene.ctx, host.nbytes, C.byref(p)))
+    host = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(h, w, 4))
+    host[:] = 0
 dev = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
 for spp in (1, 8, 32):
     scene.render_accumulate_host(host, 1, spp)

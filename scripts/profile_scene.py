@@ -6,6 +6,8 @@ sid = int(os.environ.get("SCENE", "100"))
 w, h, spp, depth = (int(os.environ.get(k, d)) for k, d in (("W", "1920"), ("H", "1080"), ("SPP", "16"), ("DEPTH", "25")))
 scene = rt.Scene.builtin(sid, w, h, max_depth=depth)
 scene.set_pipelines(1)
+if "RT_TAIL" in os.environ:
+    scene.set_tail_start(int(os.environ["RT_TAIL"]))
 for i in range(3):
     scene.render_samples(spp)
 scene.synchronize()

@@ -90,10 +90,14 @@ def test_shading_matches_golden(sid):
     assert np.abs(emit - g["shade_emitted"]).max() <= 1e-5
 
 
+@pytest.mark.parametrize("tail_start", [1 << 20, -1], ids=["per_bounce_kernels", "default_schedule"])
 @pytest.mark.parametrize("sid", GOLDEN_SCENES)
-def test_image_with_shared_random_numbers_matches_golden(sid):
+def test_image_with_shared_random_numbers_matches_golden(sid, tail_start):
+    """Images this small are rendered by the tail kernel alone under the default schedule; the first
+    variant keeps every bounce on the per-bounce kernels (raygen -> first leaves -> extend -> shade)."""
     g, w, h, depth, spp, seed = golden(sid)
     scene = rt.Scene.builtin(sid, w, h, max_depth=depth)
+    scene.set_tail_start(tail_start)
     scene.set_seed(seed)
     scene.render_samples(spp)
     acc = scene.accumulator()
@@ -288,6 +292,20 @@ def test_render_is_independent_of_batching_and_sample_splits():
     host[..., 3] = 7.0
     a.render_accumulate_host(host, first_sample=1, n_samples=6, seed=3)
     assert np.array_equal(host[..., :3], whole[..., :3]) and (host[..., 3] == 7.0).all()
+    # the same through page-locked memory from the library (the upload then runs beside the render), in two calls,
+    # with the caller changing the buffer in between (every call uploads what the buffer holds)
+    import ctypes as C
+    p = C.c_void_p()
+    a._check(a.amd.rt_host_buffer_create(a.ctx, host.nbytes, C.byref(p)))
+    locked = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=host.shape)
+    locked[:] = 0
+    a.render_accumulate_host(locked, first_sample=1, n_samples=2, seed=3)
+    locked[..., 3] = 5.0
+    a.render_accumulate_host(locked, first_sample=3, n_samples=4, seed=3)
+    assert np.array_equal(locked[..., :3], whole[..., :3]) and (locked[..., 3] == 5.0).all()
+    a.render_accumulate_host(host, first_sample=7, n_samples=1, seed=3)   # back to the pageable buffer
+    del locked
+    a._check(a.amd.rt_host_buffer_destroy(a.ctx, p))
 
 
 def test_two_pipelines_give_the_same_image_as_one():
@@ -512,10 +530,14 @@ def test_extend_kernel_stack_overflow_area(kind):
     assert check_hits(got, cpu.intersect(rays)) == 1.0
     _same_records(got, gpu.intersect(rays))
     _same_records(got, gpu.extend(rays))   # and without the counting build
-    # the same trees through a whole render (raygen -> extend -> shade), shared random numbers
-    gpu.set_seed(2)
-    gpu.render_samples(2)
-    assert np.allclose(gpu.accumulator(), cpu.render(2, seed=2), rtol=1e-5, atol=1e-6)
+    # the same trees through whole renders, shared random numbers: per-bounce kernels only, then the tail kernel only
+    want = cpu.render(2, seed=2)
+    for tail_start in (1 << 20, 0):
+        fresh = _shells(rt.Scene(), 40) if kind == "shells_small_tree" else _overlapping_cluster(rt.Scene(), 1024, np.random.default_rng(5))
+        fresh.set_tail_start(tail_start)
+        fresh.set_seed(2)
+        fresh.render_samples(2)
+        assert np.allclose(fresh.accumulator(), want, rtol=1e-5, atol=1e-6)
 
 
 def test_extend_kernel_rejects_rays_the_render_path_never_casts():
@@ -529,3 +551,21 @@ def test_extend_kernel_rejects_rays_the_render_path_never_casts():
     with pytest.raises(rt.RenderError, match="32"):
         s.extend(rays)
     assert s.extend(np.zeros(0, _abi.ray_dtype())).shape == (0,)
+
+
+@pytest.mark.parametrize("sid", [0, 3, 7, 8, 100])
+def test_tail_kernel_gives_the_same_image_wherever_it_takes_over(sid):
+    """Per-bounce kernels for every bounce, the tail kernel from bounce 0 (whole paths), from bounce 1, from bounce 3 and
+    the default schedule: one image, bit for bit (media with box boundaries in scene 7, image / noise / checker
+    textures in scenes 0, 3, 100, everything in scene 8)."""
+    w, h, spp = 72, 40, 5
+    images = []
+    for tail_start in (1 << 20, 0, 1, 3, -1):
+        s = rt.Scene.builtin(sid, w, h)
+        s.set_tail_start(tail_start)
+        s.set_seed(7)
+        s.render_samples(spp)
+        images.append(s.accumulator())
+    assert np.isfinite(images[0]).all() and images[0][..., :3].max() > 0
+    for img in images[1:]:
+        assert np.array_equal(images[0], img)
