@@ -400,6 +400,27 @@ int rt_render_accumulate_rows_device(rt_scene* scene, const rt_camera_desc* cam,
                                      uint32_t n_samples, uint32_t first_row,
                                      uint32_t n_rows, float* d_acc);
 
+/* One render call spread over several GPUs of this process: the counterpart of
+ * the reference's rows handed to rayon workers (src/camera.rs:282-304), with
+ * GPUs in place of threads.  scenes[i] is the same scene created on GPU i's
+ * context (rt_ctx_create + rt_scene_create per GPU; scenes[0]'s GPU holds
+ * d_acc).  RT_SPLIT_SAMPLES: GPU i renders its contiguous share of the sample
+ * numbers for all pixels - GPU 0 straight into d_acc, the others into private
+ * zeroed buffers that are copied to GPU 0 (peer copies over xGMI, all at once)
+ * and added to d_acc in GPU order, so the result is reproducible, and equal to
+ * the one-GPU image up to the order of the f32 additions.  RT_SPLIT_ROWS: GPU
+ * i renders all samples for its contiguous share of the rows, on top of those
+ * rows of d_acc, and the rows are copied back: bit for bit the one-GPU image
+ * (the choice for calls with few samples, such as interactive frames).
+ * The same context must not appear twice; two contexts on one GPU are
+ * accepted.  Enqueues on the contexts' streams and returns without waiting;
+ * everything has finished when scenes[0]'s context has (rt_ctx_synchronize). */
+typedef enum rt_split { RT_SPLIT_SAMPLES = 0, RT_SPLIT_ROWS = 1 } rt_split;
+int rt_render_accumulate_multi(rt_scene* const* scenes, int n_gpus, int split,
+                               const rt_camera_desc* cam, uint64_t seed,
+                               uint32_t first_sample, uint32_t n_samples,
+                               float* d_acc);
+
 /* rt_render_accumulate_device for callers that cannot allocate.  It has no
  * counterpart in the reference; it is for callers that must not reach
  * hipMalloc / hipFree: code under HIP graph capture, tight serving loops

@@ -22,6 +22,7 @@ RT_NO_TRANSFORM = 0xFFFFFFFF
 PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_QUAD, PRIM_MEDIUM = 0, 1, 2, 3
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
 FINALIZE_MEAN, FINALIZE_SQRT, FINALIZE_TONEMAP_RGBA = 0, 1, 2
+SPLIT_SAMPLES, SPLIT_ROWS = 0, 1
 
 
 class RtRay(C.Structure):
@@ -121,6 +122,7 @@ RT_ABI = {
     "rt_ctx_release_host_buffer": (C.c_int, [_P]),
     "rt_render_accumulate_device": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_render_accumulate_rows_device": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _U32, _U32, _P]),
+    "rt_render_accumulate_multi": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_render_accumulate_device_noalloc": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_finalize_device": (C.c_int, [_P, _P, _U64, _U32, C.c_int, _F, _P]),
     "rt_finalize": (C.c_int, [_P, _P, _U64, _U32, C.c_int, _F, _P]),

@@ -137,6 +137,14 @@ struct rt_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_upload = nullptr;
 
+    // rt_render_accumulate_multi: this GPU's private buffer (its share of the samples, or its rows), the buffers that
+    // the other GPUs' shares arrive in when this is the GPU that holds the image, and the events that order the two
+    float* d_partial = nullptr;
+    size_t d_partial_bytes = 0;
+    std::vector<float*> peer_in;
+    size_t peer_in_bytes = 0;
+    hipEvent_t ev_multi_ready = nullptr, ev_multi_done = nullptr;
+
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool have_render_time = false;
     std::vector<EventPair> ev_pool;
@@ -541,6 +549,10 @@ int rt_ctx_destroy(rt_ctx* c) {
     for (Pipe& p : c->pipes) destroy_pipe(p);
     if (c->d_counters) (void)hipFree(c->d_counters);
     release_host_buffer(c);
+    if (c->d_partial) (void)hipFree(c->d_partial);
+    for (float* p : c->peer_in) if (p) (void)hipFree(p);
+    if (c->ev_multi_ready) (void)hipEventDestroy(c->ev_multi_ready);
+    if (c->ev_multi_done) (void)hipEventDestroy(c->ev_multi_done);
     if (c->d_acc_cache) (void)hipFree(c->d_acc_cache);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
@@ -1383,6 +1395,98 @@ int rt_render_accumulate(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed,
     if (he != hipSuccess) return fail(RT_ERR_HIP, "accumulation buffer copy failed: %s", hipGetErrorString(he));
     if (hs != hipSuccess || hc != hipSuccess) return fail(RT_ERR_HIP, "render failed: %s", hipGetErrorString(hs != hipSuccess ? hs : hc));
     return collect_phases(c);
+}
+
+int rt_render_accumulate_multi(rt_scene* const* scenes, int n_gpus, int split, const rt_camera_desc* cam, uint64_t seed, uint32_t first_sample,
+                               uint32_t n_samples, float* d_acc) {
+    if (!scenes || !d_acc) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_gpus < 1 || n_gpus > 64) return fail(RT_ERR_INVALID_ARGUMENT, "%d GPUs: 1 to 64 are supported", n_gpus);
+    if (split != RT_SPLIT_SAMPLES && split != RT_SPLIT_ROWS) return fail(RT_ERR_INVALID_ARGUMENT, "unknown split %d", split);
+    int e = check_camera(cam);
+    if (e) return e;
+    for (int i = 0; i < n_gpus; ++i) {
+        if (!scenes[i]) return fail(RT_ERR_INVALID_ARGUMENT, "scenes[%d] is NULL", i);
+        for (int j = 0; j < i; ++j)
+            if (scenes[j]->ctx == scenes[i]->ctx) return fail(RT_ERR_INVALID_ARGUMENT, "scenes[%d] and scenes[%d] share a context: one context per share of the work", j, i);
+    }
+    if ((uint64_t)first_sample + n_samples > 0xFFFFFFFFull) return fail(RT_ERR_INVALID_ARGUMENT, "sample numbers overflow 32 bits");
+    rt_ctx* c0 = scenes[0]->ctx;
+    if (n_gpus == 1) return render_rows(scenes[0], cam, seed, first_sample, n_samples, 0, cam->height, d_acc, nullptr);
+    const size_t row_bytes = (size_t)cam->width * 4 * sizeof(float);
+    const size_t bytes = row_bytes * cam->height;
+    const unsigned long long n_pixels = (unsigned long long)cam->width * cam->height;
+    // share i of `total` units: the first (total % n) shares get one unit more, shares are contiguous and in GPU order
+    auto share = [&](uint32_t total, int i, uint32_t& first, uint32_t& count) {
+        const uint32_t base = total / (uint32_t)n_gpus, rem = total % (uint32_t)n_gpus;
+        count = base + ((uint32_t)i < rem ? 1u : 0u);
+        first = (uint32_t)i * base + std::min<uint32_t>((uint32_t)i, rem);
+    };
+    auto event_of = [](hipEvent_t& ev) -> hipError_t { return ev ? hipSuccess : hipEventCreateWithFlags(&ev, hipEventDisableTiming); };
+
+    // GPU 0 holds the image: whatever is already enqueued for d_acc on its stream comes first
+    if ((e = set_device(c0))) return e;
+    HIP_TRY(event_of(c0->ev_multi_ready));
+    HIP_TRY(hipEventRecord(c0->ev_multi_ready, c0->stream));
+    if (split == RT_SPLIT_SAMPLES && (c0->peer_in.size() < (size_t)n_gpus || c0->peer_in_bytes < bytes)) {
+        HIP_TRY(hipStreamSynchronize(c0->stream));
+        for (float* p : c0->peer_in) if (p) (void)hipFree(p);
+        c0->peer_in.assign((size_t)n_gpus, nullptr);
+        c0->peer_in_bytes = 0;
+        for (int i = 1; i < n_gpus; ++i) HIP_TRY(hipMalloc((void**)&c0->peer_in[(size_t)i], bytes));
+        c0->peer_in_bytes = bytes;
+    }
+    // every other GPU: its share into its private buffer, then the buffer (or its rows) over to GPU 0
+    for (int i = 1; i < n_gpus; ++i) {
+        rt_ctx* c = scenes[i]->ctx;
+        if ((e = set_device(c))) return e;
+        if (c->d_partial_bytes < bytes) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->d_partial) (void)hipFree(c->d_partial);
+            c->d_partial = nullptr;
+            c->d_partial_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&c->d_partial, bytes));
+            c->d_partial_bytes = bytes;
+        }
+        HIP_TRY(event_of(c->ev_multi_done));
+        uint32_t first = 0, count = 0;
+        if (split == RT_SPLIT_SAMPLES) {
+            share(n_samples, i, first, count);
+            HIP_TRY(hipMemsetAsync(c->d_partial, 0, bytes, c->stream));
+            if (count && (e = render_rows(scenes[i], cam, seed, first_sample + first, count, 0, cam->height, c->d_partial, nullptr))) return e;
+            if ((e = set_device(c))) return e;
+            HIP_TRY(hipMemcpyPeerAsync(c0->peer_in[(size_t)i], c0->device, c->d_partial, c->device, bytes, c->stream));
+        } else {
+            // its rows of the image as they are now, the new samples on top, and back: exactly what one GPU would have computed
+            share(cam->height, i, first, count);
+            if (count) {
+                float* mine = c->d_partial + (size_t)first * cam->width * 4;
+                float* theirs = d_acc + (size_t)first * cam->width * 4;
+                HIP_TRY(hipStreamWaitEvent(c->stream, c0->ev_multi_ready, 0));
+                HIP_TRY(hipMemcpyPeerAsync(mine, c->device, theirs, c0->device, row_bytes * count, c->stream));
+                if ((e = render_rows(scenes[i], cam, seed, first_sample, n_samples, first, count, c->d_partial, nullptr))) return e;
+                if ((e = set_device(c))) return e;
+                HIP_TRY(hipMemcpyPeerAsync(theirs, c0->device, mine, c->device, row_bytes * count, c->stream));
+            }
+        }
+        HIP_TRY(hipEventRecord(c->ev_multi_done, c->stream));
+    }
+    // GPU 0: its own share straight into the image, then the others' shares in GPU order
+    if ((e = set_device(c0))) return e;
+    uint32_t first = 0, count = 0;
+    if (split == RT_SPLIT_SAMPLES) {
+        share(n_samples, 0, first, count);
+        if (count && (e = render_rows(scenes[0], cam, seed, first_sample + first, count, 0, cam->height, d_acc, nullptr))) return e;
+    } else {
+        share(cam->height, 0, first, count);
+        if (count && (e = render_rows(scenes[0], cam, seed, first_sample, n_samples, first, count, d_acc, nullptr))) return e;
+    }
+    if ((e = set_device(c0))) return e;
+    for (int i = 1; i < n_gpus; ++i) {
+        HIP_TRY(hipStreamWaitEvent(c0->stream, scenes[i]->ctx->ev_multi_done, 0));
+        if (split == RT_SPLIT_SAMPLES) launch_add_buffers(c0->stream, c0->max_blocks, (float4*)d_acc, (const float4*)c0->peer_in[(size_t)i], n_pixels);
+    }
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
 }
 
 int rt_finalize_device(rt_ctx* c, const float* d_acc, uint64_t n_pixels, uint32_t total_samples, int mode, float exposure, void* d_out) {

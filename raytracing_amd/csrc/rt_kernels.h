@@ -65,6 +65,7 @@ void launch_tail(hipStream_t st, uint32_t resident_blocks, uint32_t upper_bound,
                  uint64_t seed, uint32_t first_bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, const float* thr,
                  float4* radiance, unsigned long long* stack_overflow);
 void launch_accumulate(hipStream_t st, uint32_t max_blocks, const BatchInfo& b, const float4* radiance, float4* acc);
+void launch_add_buffers(hipStream_t st, uint32_t max_blocks, float4* acc, const float4* part, unsigned long long n_pixels);
 void launch_finalize(hipStream_t st, uint32_t max_blocks, const float4* acc, unsigned long long n_pixels, float inv_samples, int mode,
                      float exposure, void* out);
 void launch_intersect(hipStream_t st, uint32_t max_blocks, const DScene& sc, uint64_t seed, const rt_ray* rays, unsigned long long n,

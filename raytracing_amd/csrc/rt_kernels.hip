@@ -1446,6 +1446,18 @@ __global__ __launch_bounds__(256) void k_accumulate(BatchInfo b, const float4* _
     }
 }
 
+// acc[pixel] += part[pixel] (x, y, z; lane 3 is left alone): the sum step of a render that was split by sample number
+// over several GPUs, applied in GPU order.
+__global__ __launch_bounds__(256) void k_add_buffers(float4* __restrict__ acc, const float4* __restrict__ part, unsigned long long n_pixels) {
+    for (unsigned long long p = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; p < n_pixels;
+         p += (unsigned long long)gridDim.x * blockDim.x) {
+        float4 a = acc[p];
+        const float4 b = part[p];
+        a.x += b.x; a.y += b.y; a.z += b.z;
+        acc[p] = a;
+    }
+}
+
 // Colour::to_rgba (src/math/vec3.rs:252-259)
 RT_D uint32_t to_rgba(float3 c) {
     float r = sqrtf(c.x) * 255.999f, g = sqrtf(c.y) * 255.999f, bl = sqrtf(c.z) * 255.999f;
@@ -1672,6 +1684,10 @@ void launch_tail(hipStream_t st, uint32_t resident_blocks, uint32_t upper_bound,
 
 void launch_accumulate(hipStream_t st, uint32_t max_blocks, const BatchInfo& b, const float4* radiance, float4* acc) {
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(b.n_pixels, max_blocks)), dim3(256), 0, st, b, radiance, acc);
+}
+
+void launch_add_buffers(hipStream_t st, uint32_t max_blocks, float4* acc, const float4* part, unsigned long long n_pixels) {
+    hipLaunchKernelGGL(k_add_buffers, dim3(grid_for(n_pixels, max_blocks)), dim3(256), 0, st, acc, part, n_pixels);
 }
 
 void launch_finalize(hipStream_t st, uint32_t max_blocks, const float4* acc, unsigned long long n_pixels, float inv_samples, int mode,

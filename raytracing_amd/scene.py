@@ -335,6 +335,14 @@ class Scene(BuilderCalls):
         cam = self.camera_desc()
         self._check(self.amd.rt_render_accumulate_device(self.rt_scene, C.byref(cam), seed, first_sample, n_samples, d_acc))
 
+    def render_accumulate_multi(self, others, d_acc, first_sample, n_samples, seed=0, split=_abi.SPLIT_SAMPLES):
+        """One render call over this scene's GPU and those of `others` (the same scene built on other contexts);
+        d_acc lives on this scene's GPU.  Returns after enqueueing; `synchronize()` of this scene waits for all."""
+        cam = self.camera_desc()
+        scenes = [self] + list(others)
+        arr = (C.c_void_p * len(scenes))(*[s.rt_scene for s in scenes])
+        self._check(self.amd.rt_render_accumulate_multi(arr, len(scenes), split, C.byref(cam), seed, first_sample, n_samples, d_acc))
+
     def render_accumulate_device_noalloc(self, d_acc, first_sample, n_samples, seed=0):
         """The variant that allocates nothing: its queues live in the library's fixed device array."""
         cam = self.camera_desc()
