@@ -35,7 +35,7 @@ def reduce_accumulators(acc, dst=None, group=None):
     """Sum the per-rank accumulation buffers (a torch tensor) in place: to every rank
     (dst=None, all-reduce) or to rank `dst` only."""
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return acc
     if dst is None:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)

@@ -12,7 +12,8 @@ from raytracing_amd import _abi
 from raytracing_amd.scene import BuilderCalls, load_earth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+# RT_ORACLE_LIBRARY: another build of the same oracle (bench.py's -march=native build for the CPU baseline)
+LIB_PATH = os.environ.get("RT_ORACLE_LIBRARY") or os.path.join(ROOT, "oracle", "liboracle.so")
 
 RNG_XOSHIRO, RNG_COUNTER = 0, 1
 
