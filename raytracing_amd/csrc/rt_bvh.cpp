@@ -41,6 +41,7 @@ struct Builder {
     float* nodes;
     std::atomic<uint32_t> next_node{0};
     std::atomic<uint32_t> max_depth{0};
+    uint32_t sah_depth = 40;  // below this depth ranges are split by count (a balanced subtree) instead of by SAH
 
     struct Task { size_t begin, end; uint32_t node; uint32_t depth; };
 
@@ -58,8 +59,10 @@ struct Builder {
         for (size_t i = b; i < e; ++i) { float c[3]; centroid(prims[i], c); cb.grow_point(c); }
         float best_cost = FLT_MAX;
         int best_axis = -1, best_bin = -1;
-        // past depth 40 split by count so that the traversal stack (64 entries) always suffices
-        for (int axis = 0; axis < 3 && depth < 40; ++axis) {
+        // SAH follows the geometry and can peel off one primitive per level (outliers at growing distances); past
+        // sah_depth ranges are split by count, which bounds the depth by sah_depth + log2(n).  Whether the stack of the
+        // traversal suffices is checked on the finished tree (stack_need); build_bvh lowers sah_depth when it does not.
+        for (int axis = 0; axis < 3 && depth < sah_depth; ++axis) {
             float lo = cb.mn[axis], hi = cb.mx[axis];
             if (!(hi > lo)) continue;
             float scale = (float)NBINS / (hi - lo);
@@ -311,7 +314,7 @@ static void renumber(FlatBvh& bvh) {
     bvh.stack_need = need[bvh.root];
 }
 
-FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads) {
+static FlatBvh build_with_sah_depth(std::vector<BuildPrim>& prims, int threads, uint32_t sah_depth) {
     FlatBvh out;
     const size_t n = prims.size();
     if (n == 0) return out;
@@ -326,6 +329,7 @@ FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads) {
     }
     out.nodes.assign(16 * (n - 1), 0.0f);
     Builder bld(prims, out.nodes.data());
+    bld.sah_depth = sah_depth;
     uint32_t root = bld.next_node.fetch_add(1);
     if (threads <= 0) threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (threads == 1 || n < 200000) {
@@ -350,6 +354,18 @@ FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads) {
     out.max_depth = bld.max_depth.load();
     if (BVH_WIDTH == 4) fold_to_four(out);
     renumber(out);
+    return out;
+}
+
+FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads) {
+    // A chain of 40 one-versus-rest splits on top of a balanced tree of millions of leaves can ask for more stack entries
+    // than the traversal has; less of the tree is then left to SAH (fewer chain levels), down to a plain split by count,
+    // whose worst case is 3 entries per level of a tree of log4(n) levels.
+    FlatBvh out;
+    for (uint32_t sah_depth : {40u, 16u, 6u, 0u}) {
+        out = build_with_sah_depth(prims, threads, sah_depth);
+        if (out.stack_need <= TRAVERSAL_STACK_ENTRIES) break;
+    }
     return out;
 }
 

@@ -21,6 +21,14 @@ struct File {
         if (!f) throw RenderError("cannot open " + path);
     }
     ~File() { if (f) std::fclose(f); }
+    // flushes and closes, reporting what the destructor could not (a full disk shows up here)
+    void close() {
+        FILE* g = f;
+        f = nullptr;
+        const bool flushed = g && std::fflush(g) == 0;
+        const bool closed = g && std::fclose(g) == 0;
+        if (g && !(flushed && closed)) throw RenderError("cannot finish writing the file");
+    }
     void put(const void* p, size_t n) { if (n && std::fwrite(p, 1, n, f) != n) throw RenderError("short write"); }
     void get(void* p, size_t n) { if (n && std::fread(p, 1, n, f) != n) throw RenderError("short read"); }
     template <class T> void put(T v) { put(&v, sizeof v); }
@@ -130,31 +138,58 @@ struct CheckpointHeader {
     char magic[8];
     uint32_t version, width, height, max_depth;
     uint64_t samples, seed;
+    uint64_t camera_hash;   // FNV-1a of the camera description the accumulation was rendered with
+    uint32_t n_leaves, _pad;
 };
-const char CHECKPOINT_MAGIC[8] = {'R', 'T', 'A', 'M', 'D', 'C', 'K', '1'};
+const char CHECKPOINT_MAGIC[8] = {'R', 'T', 'A', 'M', 'D', 'C', 'K', '2'};
+uint64_t fnv1a(const void* p, size_t n) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; ++i) h = (h ^ ((const unsigned char*)p)[i]) * 0x100000001b3ull;
+    return h;
+}
 }  // namespace
 
 void Camera::save_checkpoint(const std::string& path) {
     std::vector<float> acc = download_accumulator();
     CheckpointHeader h{};
     std::memcpy(h.magic, CHECKPOINT_MAGIC, 8);
-    h.version = 1;
+    h.version = 2;
     h.width = (uint32_t)render_resolution_.first;
     h.height = (uint32_t)render_resolution_.second;
     h.max_depth = (uint32_t)max_depth_;
     h.samples = samples_;
     h.seed = seed_;
-    File f(path, "wb");
-    f.put(h);
-    f.put(acc.data(), acc.size() * sizeof(float));
+    const rt_camera_desc cam = raytracing_camera_desc();
+    h.camera_hash = fnv1a(&cam, sizeof cam);
+    h.n_leaves = (uint32_t)flat_.world.size();
+    // written beside the target and moved over it when complete: a crash or a full disk never leaves a
+    // truncated file where the previous checkpoint was
+    const std::string tmp = path + ".tmp";
+    try {
+        File f(tmp, "wb");
+        f.put(h);
+        f.put(acc.data(), acc.size() * sizeof(float));
+        f.close();
+    } catch (...) {
+        std::remove(tmp.c_str());
+        throw;
+    }
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) {
+        std::remove(tmp.c_str());
+        throw RenderError("cannot move the checkpoint into place: " + path);
+    }
 }
 
 void Camera::load_checkpoint(const std::string& path) {
     File f(path, "rb");
     CheckpointHeader h = f.get<CheckpointHeader>();
-    if (std::memcmp(h.magic, CHECKPOINT_MAGIC, 8) != 0 || h.version != 1) throw RenderError("not a checkpoint of this library: " + path);
+    if (std::memcmp(h.magic, CHECKPOINT_MAGIC, 8) != 0 || h.version != 2) throw RenderError("not a checkpoint of this library: " + path);
     if (h.width != render_resolution_.first || h.height != render_resolution_.second || h.max_depth != max_depth_)
         throw RenderError("checkpoint was written for another resolution or depth");
+    // resuming adds samples to the sums in the file: they must be sums of the same image
+    const rt_camera_desc cam = raytracing_camera_desc();
+    if (h.camera_hash != fnv1a(&cam, sizeof cam) || h.n_leaves != (uint32_t)flat_.world.size())
+        throw RenderError("checkpoint was written for another camera pose or another scene");
     std::vector<float> acc(4 * (size_t)h.width * h.height);
     f.get(acc.data(), acc.size() * sizeof(float));
     upload_accumulator(acc.data(), (size_t)h.samples);

@@ -451,8 +451,8 @@ void Camera::render_samples(uint32_t n) {
     if (n == 0) return;
     update_raytracing_camera();
     uint32_t first = (uint32_t)samples_ + 1;  // the reference passes the 1-based sample number (:82-83)
-    samples_ += n;
     check(rt_render_accumulate_device(scene_, &rt_cam_, seed_, first, n, d_acc_), "rt_render_accumulate_device");
+    samples_ += n;  // only once the samples are on their way: a refused call leaves the count as it was
 }
 
 void Camera::empty_render() { render_samples(1); }  // :80-85

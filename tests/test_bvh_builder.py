@@ -58,6 +58,21 @@ def test_chain_shaped_tree_stays_within_the_traversal_stack():
     assert rep.depth >= 15 and rep.stack_need <= 64
 
 
+def test_outliers_on_top_of_a_cluster_are_rebuilt_with_a_shallower_sah_part():
+    """Sixty outliers at tripling distances over a cluster of a thousand small boxes: with SAH down to depth 40 the
+    one-versus-rest chain plus the cluster's own levels would need 78 stack entries; the builder then leaves less of
+    the tree to SAH until the worst case fits the 64 entries of the traversal stack."""
+    rng = np.random.default_rng(0)
+    c = rng.uniform(0, 1, (1000, 3))
+    cluster = np.concatenate([c - 0.001, c + 0.001], axis=1)
+    k = np.arange(1, 61, dtype=np.float64)
+    far = np.zeros((60, 6))
+    far[:, 0], far[:, 3], far[:, 4], far[:, 5] = 3.0 ** k, 3.0 ** k + 1, 1, 1
+    rep = check(np.concatenate([cluster, far]))
+    assert rep.violations == 0 and rep.leaves_found == 1060
+    assert rep.stack_need <= 64
+
+
 def test_sah_tree_is_cheaper_than_a_shuffled_insertion_order_would_suggest():
     """The surface-area cost of the tree does not depend on the order the leaves are handed in."""
     rng = np.random.default_rng(3)

@@ -569,3 +569,39 @@ def test_tail_kernel_gives_the_same_image_wherever_it_takes_over(sid):
     assert np.isfinite(images[0]).all() and images[0][..., :3].max() > 0
     for img in images[1:]:
         assert np.array_equal(images[0], img)
+
+
+def test_bvh_stress_scene_at_size_properties():
+    """Two million random spheres (primary + one bounce), no CPU render of that size: finite and non-negative output,
+    one sample + one sample = two samples, independence of the batch size, and traversal stacks deeper than the
+    extend kernel's LDS levels (the global overflow area in use) - all bit for bit."""
+    import ctypes as C
+    w, h = 480, 270
+    s = rt.Scene.builtin(102, w, h, max_depth=2, stress_count=2_000_000)
+    assert s.info()["leaves_in_tree"] + s.info()["leaves_tested_first"] == 2_000_000
+    nbytes = w * h * 16
+
+    def render(calls, batch_paths=0, counters=False):
+        d = C.c_void_p()
+        s._check(s.amd.rt_buffer_create(s.ctx, nbytes, C.byref(d)))
+        s._check(s.amd.rt_buffer_zero(s.ctx, d, nbytes))
+        s.set_batch_paths(batch_paths)
+        s.set_counters(counters)
+        for first, count in calls:
+            s.render_accumulate_device(d, first, count, seed=3)
+        out = np.empty((h, w, 4), np.float32)
+        s._check(s.amd.rt_buffer_download(s.ctx, out.ctypes.data, d, nbytes))
+        s._check(s.amd.rt_buffer_destroy(s.ctx, d))
+        s.set_counters(False)
+        s.set_batch_paths(0)
+        return out
+
+    two = render([(1, 2)])
+    assert np.isfinite(two).all() and (two[..., :3] >= 0).all() and (two[..., 3] == 0).all() and two[..., :3].max() > 0
+    assert np.array_equal(render([(1, 1), (2, 1)]), two)
+    assert np.array_equal(render([(1, 2)], batch_paths=50_000), two)
+    counted = render([(1, 2)], counters=True)             # the counting build of the kernels, per-bounce kernels only
+    c = s.counters(reset=True)
+    assert np.array_equal(counted, two)
+    assert c["max_stack"] > 12, c
+    assert c["samples"] == 2 * w * h and c["segments"] >= c["samples"]

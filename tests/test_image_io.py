@@ -115,3 +115,18 @@ def test_checkpoint_resumes_the_same_render(tmp_path):
     other = rt.Scene.builtin(8, 41, 24)
     with pytest.raises(rt.RenderError):
         other.load_checkpoint(str(tmp_path / "ck.bin"))
+    # sums of another image must not be continued: a camera that has turned, another scene of the same size
+    turned = rt.Scene.builtin(8, 40, 24)
+    turned.change_pitch_yaw_by(0.0, 5.0)
+    with pytest.raises(rt.RenderError, match="another camera pose"):
+        turned.load_checkpoint(str(tmp_path / "ck.bin"))
+    with pytest.raises(rt.RenderError, match="another camera pose or another scene"):
+        rt.Scene.builtin(6, 40, 24).load_checkpoint(str(tmp_path / "ck.bin"))
+    # the file is written beside the target and moved into place: nothing else is left behind, and a second save
+    # replaces the first
+    first.render_samples(1)
+    first.save_checkpoint(str(tmp_path / "ck.bin"))
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["ck.bin"]
+    third = rt.Scene.builtin(8, 40, 24)
+    third.load_checkpoint(str(tmp_path / "ck.bin"))
+    assert third.samples == 4
