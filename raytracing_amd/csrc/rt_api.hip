@@ -799,20 +799,18 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
             o3[0] = l[1] * r[2] - l[2] * r[1]; o3[1] = l[2] * r[0] - l[0] * r[2]; o3[2] = l[0] * r[1] - l[1] * r[0];
         };
         auto dotf = [](const float* l, const float* r) { return ((l[0] * r[0] + l[1] * r[1]) + l[2] * r[2]) + 0.0f; };
-        float n[3], N[3], w[3], A[3], B[3];
+        float n[3], N[3], w[3];
         crossf(uf, vf, n);
         float inv_len = 1.0f / std::sqrt(dotf(n, n));
         for (int a = 0; a < 3; ++a) N[a] = inv_len * n[a];
         float D = dotf(N, qf);
         float inv_nn = 1.0f / dotf(n, n);
         for (int a = 0; a < 3; ++a) w[a] = inv_nn * n[a];
-        crossf(vf, w, A);
-        crossf(w, uf, B);
         float4* o = &quads[4 * (size_t)i];
         o[0] = make_float4(N[0], N[1], N[2], D);
-        o[1] = make_float4(qf[0], qf[1], qf[2], __builtin_bit_cast(float, qd.material));
-        o[2] = make_float4(A[0], A[1], A[2], __builtin_bit_cast(float, qd.prim_id));
-        o[3] = make_float4(B[0], B[1], B[2], __builtin_bit_cast(float, qd.transform));
+        o[1] = make_float4(qf[0], qf[1], qf[2], w[0]);
+        o[2] = make_float4(uf[0], uf[1], uf[2], w[1]);
+        o[3] = make_float4(vf[0], vf[1], vf[2], w[2]);
         fill_meta(&quad_meta[2 * (size_t)i], qd.material, qd.prim_id, qd.transform);
         if (qd.transform == RT_NO_TRANSFORM) {
             float quv[3], qu[3], qv[3];

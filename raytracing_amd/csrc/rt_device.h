@@ -48,10 +48,10 @@ RT_HD bool ref_placed(uint32_t r) { return (r & REF_PLACED) != 0; }
 //           ray walks sits in a few KB at the start of the array), depth-first below.
 //   spheres 1 x float4: centre.xyz, radius                      (16 B)
 //   moving  2 x float4: centre0.xyz, radius | dcentre.xyz, 0     (32 B)
-//   quads   4 x float4: N.xyz, D | q.xyz, bits(material) |
-//                       A.xyz, bits(prim_id) | B.xyz, bits(transform)  (64 B)
-//           N = unit(u x v), D = N.q, w = n/(n.n), A = v x w, B = w x u so that
-//           alpha = (p-q).A and beta = (p-q).B (src/hittable.rs:372-408)
+//   quads   4 x float4: N.xyz, D | q.xyz, w.x | u.xyz, w.y | v.xyz, w.z  (64 B)
+//           N = unit(u x v), D = N.q, w = n/(n.n): the per-call constants of Quad::hit
+//           (src/hittable.rs:373-375); alpha = w.((p-q) x v), beta = w.(u x (p-q)) are then
+//           evaluated as the reference evaluates them (:389-391)
 //   *_meta  2 x uint4 per leaf (spheres, moving spheres, quads, media): what shading needs in
 //           one 32-byte read: material, prim_id, transform (or RT_NO_TRANSFORM),
 //           class | material kind << 8 | texture kind << 16  ||  bits(param), bits(r, g, b of a

@@ -57,7 +57,15 @@ RT_D bool sphere_root(float3 centre, float radius, float3 o, float3 d, float a, 
     return true;
 }
 
-// Quad::hit (src/hittable.rs:372-398) with the per-quad constants hoisted:
+// The plane coordinates of Quad::hit (src/hittable.rs:389-391), in its operation order: alpha = w . (h x v),
+// beta = w . (u x h) with h = hit point - q.  q4: the quad's record (layout in rt_device.h).
+RT_D void quad_alpha_beta(float4 qq, float4 uu, float4 vv, float3 p, float& alpha, float& beta) {
+    const float3 h = p - f3(qq), w = f3(qq.w, uu.w, vv.w);
+    alpha = dot3(w, cross3(h, f3(vv)));
+    beta = dot3(w, cross3(f3(uu), h));
+}
+
+// Quad::hit (src/hittable.rs:372-398) with the per-quad constants N, D, w hoisted:
 // closed interval tmin <= t <= tmax, 0 <= alpha, beta <= 1.
 RT_D bool quad_root(const float4* __restrict__ q4, float3 o, float3 d, float tmin, float tmax, float& t) {
     float4 nd = q4[0];
@@ -66,11 +74,13 @@ RT_D bool quad_root(const float4* __restrict__ q4, float3 o, float3 d, float tmi
     if (fabsf(denom) < 1e-8f) return false;
     float tt = (nd.w - dot3(N, o)) / denom;
     if (!(tmin <= tt && tt <= tmax)) return false;
-    float4 qq = q4[1], A = q4[2], B = q4[3];
-    float3 h = (o + tt * d) - f3(qq);
-    float alpha = dot3(h, f3(A));
-    float beta = dot3(h, f3(B));
-    if (!(0.0f <= alpha && alpha <= 1.0f && 0.0f <= beta && beta <= 1.0f)) return false;
+    // alpha first, beta only when alpha is inside: fewer values are live at a time (the traversal kernel has few registers to spare)
+    const float4 qq = q4[1], vv = q4[3];
+    const float3 h = (o + tt * d) - f3(qq), w = f3(qq.w, q4[2].w, vv.w);
+    const float alpha = dot3(w, cross3(h, f3(vv)));
+    if (!(0.0f <= alpha && alpha <= 1.0f)) return false;
+    const float beta = dot3(w, cross3(f3(q4[2]), h));
+    if (!(0.0f <= beta && beta <= 1.0f)) return false;
     t = tt;
     return true;
 }
@@ -529,15 +539,13 @@ RT_D HitGeom resolve_hit(const DScene& sc, uint32_t ref, const uint4& m0, float3
     float4 rot = make_float4(0, 0, 0, 0), off = rot;
     if (kind == KIND_QUAD) {
         const float4* q4 = sc.quads + 4 * (size_t)idx;
-        float4 nd = q4[0], qq = q4[1], A = q4[2], B = q4[3];
+        float4 nd = q4[0], qq = q4[1], uu = q4[2], vv = q4[3];
         if (placed) {
             rot = sc.quad_xf[2 * (size_t)idx]; off = sc.quad_xf[2 * (size_t)idx + 1];
             ray_to_object(rot, off, o, d);
         }
         g.p = o + t * d;
-        float3 h = g.p - f3(qq);
-        g.u = dot3(h, f3(A));
-        g.v = dot3(h, f3(B));
+        quad_alpha_beta(qq, uu, vv, g.p, g.u, g.v);
         set_face_normal(g, d, f3(nd));
     } else {
         float3 c;

@@ -70,6 +70,10 @@ def test_primary_rays_and_hits_match_golden(sid):
     assert rays.tobytes() == g["rays"].tobytes(), "primary rays are not bit-identical to get_ray"
     exact = check_hits(scene.intersect(g["rays"], seed=seed), g["hits"])
     exact2 = check_hits(scene.intersect(g["rays2"], seed=seed), g["hits2"])
+    if sid == 6:  # quads only: alpha and beta are evaluated in the reference's order, so (u, v) agree bit for bit as well
+        got = scene.intersect(g["rays"], seed=seed)
+        same = (got["hit"] == 1) & (g["hits"]["hit"] == 1) & (got["prim_id"] == g["hits"]["prim_id"])
+        assert np.array_equal(got["u"][same], g["hits"]["u"][same]) and np.array_equal(got["v"][same], g["hits"]["v"][same])
     if sid not in (1, 7, 8):  # no media: every t is bit-identical
         assert exact == 1.0 and exact2 == 1.0
     else:
