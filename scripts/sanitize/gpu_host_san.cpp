@@ -23,6 +23,7 @@ const char* rth_last_error();
 }
 #define CHECK(x) do { int rc_ = (x); if (rc_) { printf("FAILED %s: %d %s / %s\n", #x, rc_, rth_last_error(), rt_last_error()); return 1; } } while (0)
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);  // what was printed survives an abort
     const uint32_t W = 96, H = 64;
     std::vector<uint8_t> earth(1024 * 512 * 3, 128);
     for (int id : {0, 1, 2, 3, 4, 5, 6, 7, 8, 100, 101, 102}) {
@@ -56,6 +57,36 @@ int main() {
         CHECK(rt_primary_rays(ctx, &cam, 9, 1, pixels.data(), n, rays.data()));
         CHECK(rt_intersect_batch(sc, rays.data(), n, 9, hits.data()));
         CHECK(rt_shade_batch(sc, rays.data(), hits.data(), n, 9, out_rays.data(), att.data(), emit.data()));
+        // the render path's traversal kernels on the same rays; the entry point that allocates nothing; the tail kernel
+        // from bounce 0 and never; a second context on the same GPU for the multi-GPU entry point (samples, then rows)
+        std::vector<rt_hit> hits2(n);
+        CHECK(rt_extend_batch(sc, rays.data(), n, 9, hits2.data()));
+        for (size_t i = 0; i < n; ++i)
+            if (hits2[i].hit != hits[i].hit || hits2[i].t != hits[i].t) { printf("scene %d: extend and intersect differ at ray %zu\n", id, i); return 1; }
+        void* d_acc = nullptr;
+        CHECK(rt_buffer_create(ctx, W * H * 16, &d_acc));
+        CHECK(rt_buffer_zero(ctx, d_acc, W * H * 16));
+        CHECK(rt_render_accumulate_device_noalloc(sc, &cam, 5, 1, 2, (float*)d_acc));
+        for (int start : {0, 1 << 20, -1}) {
+            CHECK(rt_ctx_set_tail_start(ctx, start));
+            CHECK(rt_render_accumulate_device(sc, &cam, 5, 3, 2, (float*)d_acc));
+        }
+        void* h2 = rth_scene_builtin(id, W, H, 12, earth.data(), 1024, 512, 20000, 0);
+        if (!h2) { printf("scene %d (second context): %s\n", id, rth_last_error()); return 1; }
+        rt_scene* both[2] = {sc, rth_scene(h2)};
+        CHECK(rt_render_accumulate_multi(both, 2, RT_SPLIT_SAMPLES, &cam, 5, 7, 3, (float*)d_acc));
+        CHECK(rt_render_accumulate_multi(both, 2, RT_SPLIT_ROWS, &cam, 5, 10, 1, (float*)d_acc));
+        CHECK(rt_ctx_synchronize(ctx));
+        CHECK(rt_buffer_download(ctx, host_acc.data(), d_acc, W * H * 16));
+        CHECK(rt_buffer_destroy(ctx, d_acc));
+        rth_scene_free(h2);
+        void* locked = nullptr;
+        CHECK(rt_host_buffer_create(ctx, W * H * 16, &locked));
+        std::memset(locked, 0, W * H * 16);
+        CHECK(rt_render_accumulate(sc, &cam, 5, 1, 2, (float*)locked));
+        CHECK(rt_render_accumulate(sc, &cam, 5, 3, 1, host_acc.data()));
+        CHECK(rt_ctx_release_host_buffer(ctx));
+        CHECK(rt_host_buffer_destroy(ctx, locked));
         rt_scene_info info;
         CHECK(rt_scene_get_info(sc, &info));
         double sum = 0;
