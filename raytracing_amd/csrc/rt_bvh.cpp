@@ -157,9 +157,9 @@ struct Builder {
 
 }  // namespace
 
-// Folds the binary tree into one with four children per node: a node takes over the children of
-// inner children, largest box first, until its four slots are full.  Boxes, references and slack factors are copied
-// unchanged, so what is tested for a leaf does not depend on the width.
+// Folds the binary tree into one with four children per node: a node takes over children of its inner children,
+// whichever way gives the whole tree the least summed box surface of its nodes.  Boxes, references and slack factors
+// are copied unchanged, so what is tested for a leaf does not depend on the width.
 // Wide node (32 floats): child k's min.x min.y max.x max.y at 4k; z ranges (min, max) at 16 + 2k;
 // references at 24 + k; slack at 28 + k (0 marks an empty slot: such a child is never entered).
 static void fold_to_four(FlatBvh& bvh) {
@@ -179,6 +179,49 @@ static void fold_to_four(FlatBvh& bvh) {
     };
     std::vector<float> out;
     out.reserve(in.size());
+    // Which binary nodes become wide nodes: chosen so that the summed box surface of the wide nodes - the expected number of
+    // node visits of a random ray - is smallest.  T[n][j]: least cost of the subtree below binary node n when it may take up
+    // to j + 1 slots of its parent; either n becomes a wide node itself (one slot; its own surface plus the cost of spreading its
+    // subtree over four slots), or its two sides share the slots (split[n][j] of them go to the left side).
+    std::vector<std::array<float, 4>> T(n2, std::array<float, 4>{0, 0, 0, 0});
+    std::vector<std::array<uint8_t, 4>> split(n2, std::array<uint8_t, 4>{0, 0, 0, 0}), as_node(n2, std::array<uint8_t, 4>{1, 0, 0, 0});
+    {
+        auto surface = [&](uint32_t node) {
+            const Child a = child_of(node, 0), b = child_of(node, 1);
+            const double dx = (double)std::max(a.xy[2], b.xy[2]) - std::min(a.xy[0], b.xy[0]), dy = (double)std::max(a.xy[3], b.xy[3]) - std::min(a.xy[1], b.xy[1]),
+                         dz = (double)std::max(a.z[1], b.z[1]) - std::min(a.z[0], b.z[0]);
+            return dx * dy + dy * dz + dz * dx;
+        };
+        // children after parents in `post`, so walking it backwards sees children first
+        std::vector<uint32_t> post{bvh.root};
+        for (size_t i = 0; i < post.size(); ++i)
+            for (int side = 0; side < 2; ++side) {
+                const uint32_t r = child_of(post[i], side).ref;
+                if (!(r & 0x80000000u)) post.push_back(r);
+            }
+        auto cost = [&](uint32_t ref, int slots) { return (ref & 0x80000000u) ? 0.0 : (double)T[ref][(size_t)slots - 1]; };
+        for (size_t i = post.size(); i-- > 0;) {
+            const uint32_t n = post[i], l = child_of(n, 0).ref, r = child_of(n, 1).ref;
+            double forest[5] = {0, 0, 0, 0, 0};
+            uint8_t best[5] = {0, 0, 1, 1, 1};
+            for (int k = 2; k <= 4; ++k) {
+                forest[k] = cost(l, 1) + cost(r, k - 1);
+                for (int li = 2; li < k; ++li) {
+                    const double c = cost(l, li) + cost(r, k - li);
+                    if (c < forest[k]) { forest[k] = c; best[k] = (uint8_t)li; }
+                }
+            }
+            const double own = surface(n) + forest[4];
+            T[n][0] = (float)own;
+            for (int k = 2; k <= 4; ++k) {
+                const bool node = own <= forest[k];
+                T[n][(size_t)k - 1] = (float)(node ? own : forest[k]);
+                as_node[n][(size_t)k - 1] = node;
+                split[n][(size_t)k - 1] = best[k];
+            }
+            split[n][0] = best[4];  // how a wide node at n deals out its four slots
+        }
+    }
     std::vector<uint32_t> new_of(n2, 0xFFFFFFFFu);
     // pass 1: which binary nodes survive (the root, and every inner node that ends up as a child slot), in visiting order
     std::vector<uint32_t> order{bvh.root};
@@ -189,24 +232,19 @@ static void fold_to_four(FlatBvh& bvh) {
     std::vector<uint32_t> depth{1};
     for (size_t head = 0; head < order.size(); ++head) {
         const uint32_t node = order[head];
-        // start from the node's two children; while a slot is free, replace the inner child with the largest
-        // box surface by its own two children
         std::array<Child, 4> slots{};
         int k = 0;
-        slots[k++] = child_of(node, 0);
-        slots[k++] = child_of(node, 1);
-        auto area = [](const Child& c) {
-            float dx = c.xy[2] - c.xy[0], dy = c.xy[3] - c.xy[1], dz = c.z[1] - c.z[0];
-            return dx * dy + dy * dz + dz * dx;
-        };
-        while (k < 4) {
-            int pick = -1;
-            for (int i = 0; i < k; ++i)
-                if (!(slots[i].ref & 0x80000000u) && (pick < 0 || area(slots[i]) > area(slots[pick]))) pick = i;
-            if (pick < 0) break;
-            const uint32_t inner = slots[pick].ref;
-            slots[pick] = child_of(inner, 0);
-            slots[k++] = child_of(inner, 1);
+        // deal the node's four slots out as the table says
+        struct Item { uint32_t parent; int side, slots; };
+        Item todo[8] = {{node, 1, 4 - split[node][0]}, {node, 0, split[node][0]}};  // at most four items wait at a time
+        int n_todo = 2;
+        while (n_todo > 0) {
+            const Item it = todo[--n_todo];
+            const Child c = child_of(it.parent, it.side);
+            if ((c.ref & 0x80000000u) || it.slots == 1 || as_node[c.ref][(size_t)it.slots - 1]) { slots[k++] = c; continue; }
+            const int li = split[c.ref][(size_t)it.slots - 1];
+            todo[n_todo++] = Item{c.ref, 1, it.slots - li};
+            todo[n_todo++] = Item{c.ref, 0, li};
         }
         for (int i = 0; i < k; ++i) {
             if (!(slots[i].ref & 0x80000000u)) {

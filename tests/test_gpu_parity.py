@@ -490,10 +490,10 @@ def test_extend_kernel_matches_golden_and_intersect(sid):
 
 
 def _shells(s, n):
-    """n concentric spheres, radii growing by a quarter each: from the common centre a ray is inside every box, so
+    """n concentric spheres, radii growing by a twentieth each: from the common centre a ray is inside every box, so
     nothing on the traversal stack is ever dropped and the stack gets as deep as the tree allows."""
     mats = [s.lambertian(s.tex_solid(0.2 + 0.01 * i, 0.5, 0.5)) for i in range(4)]
-    s.set_world(s.bvh([s.sphere((0, 0, 0), float(1.25 ** i), mats[i % 4]) for i in range(n)]))
+    s.set_world(s.bvh([s.sphere((0, 0, 0), float(1.05 ** i), mats[i % 4]) for i in range(n)]))
     s.camera((0, 0, 0), 32, 32, max_depth=4, vfov=90.0, background=(1, 1, 1), yaw=90.0)
     return s
 
@@ -512,7 +512,7 @@ def test_extend_kernel_stack_overflow_area(kind):
     tree, 12 otherwise): the deeper levels live in the global overflow area.  The work counters report the deepest
     stack any ray had, which must be beyond the LDS levels; the hits must still be the oracle's."""
     if kind == "shells_small_tree":
-        gpu, cpu, lds_levels = _shells(rt.Scene(), 40), _shells(ob.OracleScene(), 40), 8
+        gpu, cpu, lds_levels = _shells(rt.Scene(), 150), _shells(ob.OracleScene(), 150), 8
     else:
         gpu = _overlapping_cluster(rt.Scene(), 1024, np.random.default_rng(5))
         cpu, lds_levels = _overlapping_cluster(ob.OracleScene(), 1024, np.random.default_rng(5)), 12
@@ -537,7 +537,7 @@ def test_extend_kernel_stack_overflow_area(kind):
     # the same trees through whole renders, shared random numbers: per-bounce kernels only, then the tail kernel only
     want = cpu.render(2, seed=2)
     for tail_start in (1 << 20, 0):
-        fresh = _shells(rt.Scene(), 40) if kind == "shells_small_tree" else _overlapping_cluster(rt.Scene(), 1024, np.random.default_rng(5))
+        fresh = _shells(rt.Scene(), 150) if kind == "shells_small_tree" else _overlapping_cluster(rt.Scene(), 1024, np.random.default_rng(5))
         fresh.set_tail_start(tail_start)
         fresh.set_seed(2)
         fresh.render_samples(2)
