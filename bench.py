@@ -284,7 +284,8 @@ def main():
                               "achieved": round(ext_bytes / (iso_ms * 1e-3) / 1e9, 2) if iso_ms > 0 else 0.0,
                               "frac": round(ext_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso_ms > 0 else 0.0},
                     "valu": {"achieved": round(achieved_tf, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(achieved_tf / FP32_VECTOR_PEAK_TFLOPS, 5)},
+                             "frac": round(achieved_tf / FP32_VECTOR_PEAK_TFLOPS, 5),
+                             "issue": traffic.get("extend_issue")},  # what the kernel is bound by: instruction issue x lane occupancy (PMC)
                     "pipeline": {"note": "the whole step against the HBM peak: (128 B x segments + 32 B x samples) / ms_per_step of the timed region",
                                  "bytes_per_step": pipe_bytes, "achieved": round(pipe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
