@@ -144,6 +144,7 @@ struct rt_ctx {
     std::vector<float*> peer_in;
     size_t peer_in_bytes = 0;
     hipEvent_t ev_multi_ready = nullptr, ev_multi_done = nullptr;
+    uint64_t peer_asked = 0;  // GPUs this one has asked the runtime for direct access to (bit per device)
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool have_render_time = false;
@@ -535,7 +536,7 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
     if (e != hipSuccess) {
-        delete c;
+        (void)rt_ctx_destroy(c);  // frees whatever was created before the step that failed
         return fail(RT_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
     }
     *out = c;
@@ -1437,6 +1438,13 @@ int rt_render_accumulate_multi(rt_scene* const* scenes, int n_gpus, int split, c
     for (int i = 1; i < n_gpus; ++i) {
         rt_ctx* c = scenes[i]->ctx;
         if ((e = set_device(c))) return e;
+        if (c->device != c0->device && c0->device < 64 && !(c->peer_asked >> c0->device & 1u)) {
+            // copies between the two GPUs go over their direct link when the runtime grants access (through host memory
+            // otherwise: slower, same result); asked once per pair
+            (void)hipDeviceEnablePeerAccess(c0->device, 0);
+            (void)hipGetLastError();
+            c->peer_asked |= 1ull << c0->device;
+        }
         if (c->d_partial_bytes < bytes) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->d_partial) (void)hipFree(c->d_partial);
