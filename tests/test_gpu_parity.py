@@ -593,6 +593,29 @@ def test_axis_parallel_rays_and_origins_on_box_planes(sid):
     assert want["hit"][keep].mean() > 0.2
 
 
+@pytest.mark.parametrize("sid", [0, 6, 8])
+def test_very_long_and_very_short_direction_vectors(sid):
+    """Directions are not normalised anywhere on the path (src/camera.rs:318), so t scales inversely with their length: camera
+    rays with directions scaled by 1e-30 ... 1e18 (denormal products, a = |d|^2 under- and overflowing, |denom| < 1e-8 turning
+    quads parallel) must give the restatement's decisions, and bit-equal t outside media."""
+    gpu, cpu = rt.Scene.builtin(sid, 48, 32, max_depth=4), ob.OracleScene.builtin(sid, 48, 32, max_depth=4)
+    base = gpu.primary_rays(np.arange(48 * 32, dtype=np.uint32), 1)
+    for scale in (1e-30, 1e-20, 1e-12, 1e-8, 1e-4, 1e4, 1e8, 1e12, 1e18):
+        rays = base.copy()
+        rays["direction"] = (rays["direction"].astype(np.float64) * scale).astype(np.float32)
+        want = cpu.intersect(rays)
+        for got in (gpu.intersect(rays), gpu.extend(rays)):
+            assert np.array_equal(got["hit"], want["hit"]), scale
+            both = got["hit"] == 1
+            assert np.array_equal(got["prim_id"][both], want["prim_id"][both]), scale
+            if sid != 8:
+                assert np.array_equal(got["t"][both], want["t"][both]), scale
+            else:
+                with np.errstate(all="ignore"):
+                    rel = np.abs(got["t"][both] - want["t"][both]) / np.abs(want["t"][both])
+                assert np.nanmax(rel, initial=0.0) <= 1e-6, scale
+
+
 def test_extend_kernel_rejects_rays_the_render_path_never_casts():
     s = rt.Scene.builtin(6, 16, 16)
     rays = s.primary_rays(np.arange(4, dtype=np.uint32), 1)
