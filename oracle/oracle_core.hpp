@@ -377,9 +377,10 @@ struct PerlinNoise {
         for (int64_t di = 0; di < 2; ++di)
             for (int64_t dj = 0; dj < 2; ++dj)
                 for (int64_t dk = 0; dk < 2; ++dk)
-                    c[di][dj][dk] = rand_floats[(perm_x[(size_t)((i + di) & 255) % n] ^
-                                                 perm_y[(size_t)((j + dj) & 255) % n] ^
-                                                 perm_z[(size_t)((k + dk) & 255) % n]) % n];
+                    // (i + di) wraps in the reference's release build; unsigned arithmetic says so without overflow
+                    c[di][dj][dk] = rand_floats[(perm_x[(size_t)(((uint64_t)i + (uint64_t)di) & 255) % n] ^
+                                                 perm_y[(size_t)(((uint64_t)j + (uint64_t)dj) & 255) % n] ^
+                                                 perm_z[(size_t)(((uint64_t)k + (uint64_t)dk) & 255) % n]) % n];
         float uu = u * u * (3.0f - 2.0f * u);
         float vv = v * v * (3.0f - 2.0f * v);
         float ww = w * w * (3.0f - 2.0f * w);

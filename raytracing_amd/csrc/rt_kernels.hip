@@ -605,15 +605,27 @@ struct PerlinLds {
     RT_D float4 vec(uint32_t i) const { return f4(vecs[i]); }
     RT_D uint32_t permuted(uint32_t i) const { return perm[i]; }
 };
+// (i & 255, (i + 1) & 255) for i = f as isize, f a whole number (src/perlin_noise.rs:47-49): the cast saturates at the ends of
+// the 64-bit range and maps NaN to 0, the addition wraps.  From 2^31 on every f32 is a multiple of 256.
+RT_D void lattice_bytes(float f, uint32_t (&b)[2]) {
+    const bool small = fabsf(f) < 2147483648.0f;                 // false for NaN as well
+    const bool top = f >= 9223372036854775808.0f;                // isize::MAX = ...ff, + 1 wraps to isize::MIN = ...00
+    const int i = (int)(small ? f : 0.0f);
+    b[0] = small ? (uint32_t)i & 255u : (top ? 255u : 0u);
+    b[1] = small ? (uint32_t)(i + 1) & 255u : (top ? 0u : 1u);
+}
 template <class Tables>
 RT_D float perlin_noise(const Tables& pn, float3 p) {
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     float u = p.x - fx, v = p.y - fy, w = p.z - fz;
-    int i = (int)fx, j = (int)fy, k = (int)fz;
+    uint32_t i[2], j[2], k[2];
+    lattice_bytes(fx, i);
+    lattice_bytes(fy, j);
+    lattice_bytes(fz, k);
     // the tables are expanded at scene creation (DPerlin), which takes the `% point_count` out of every lookup
-    uint32_t ix[2] = {pn.permuted(i & 255), pn.permuted((i + 1) & 255)};
-    uint32_t iy[2] = {pn.permuted(256 + (j & 255)), pn.permuted(256 + ((j + 1) & 255))};
-    uint32_t iz[2] = {pn.permuted(512 + (k & 255)), pn.permuted(512 + ((k + 1) & 255))};
+    uint32_t ix[2] = {pn.permuted(i[0]), pn.permuted(i[1])};
+    uint32_t iy[2] = {pn.permuted(256 + j[0]), pn.permuted(256 + j[1])};
+    uint32_t iz[2] = {pn.permuted(512 + k[0]), pn.permuted(512 + k[1])};
     float uu = u * u * (3.0f - 2.0f * u);
     float vv = v * v * (3.0f - 2.0f * v);
     float ww = w * w * (3.0f - 2.0f * w);

@@ -94,6 +94,60 @@ def test_shading_matches_golden(sid):
     assert np.abs(emit - g["shade_emitted"]).max() <= 1e-5
 
 
+@pytest.mark.parametrize("sid", [0, 3, 7, 8, 100])
+def test_shading_of_hits_of_very_long_and_very_short_rays(sid):
+    """Material::scatter / emitted where unit(direction) under- or overflows (|d| from 1e-25 to 1e18): the same Some / None, the
+    same NaN pattern, directions to 1e-5 of their size, origins bit for bit."""
+    gpu, cpu = rt.Scene.builtin(sid, 48, 32, max_depth=4), ob.OracleScene.builtin(sid, 48, 32, max_depth=4)
+    base = gpu.primary_rays(np.arange(48 * 32, dtype=np.uint32), 1)
+    for scale in (1e-25, 1e-19, 1e-10, 1e-3, 1e3, 1e10, 1e18):
+        rays = base.copy()
+        rays["direction"] = (rays["direction"].astype(np.float64) * scale).astype(np.float32)
+        hits = cpu.intersect(rays)
+        keep = hits["hit"] == 1
+        if not keep.any():
+            continue
+        sc_c, att_c, em_c = cpu.shade(rays[keep], hits[keep], seed=3)
+        sc_g, att_g, em_g = gpu.shade(rays[keep], hits[keep], seed=3)
+        assert np.array_equal(sc_g["tmin"], sc_c["tmin"]), scale
+        assert np.array_equal(sc_g["origin"], sc_c["origin"], equal_nan=True), scale
+        assert np.array_equal(np.isnan(sc_g["direction"]), np.isnan(sc_c["direction"])), scale
+        with np.errstate(all="ignore"):
+            size = np.maximum(1e-30, np.abs(sc_c["direction"]).max(axis=1, keepdims=True))
+            assert np.nan_to_num(np.abs(sc_g["direction"] - sc_c["direction"]) / size).max() <= 1e-5, scale
+        assert np.array_equal(np.isnan(att_g), np.isnan(att_c)) and np.abs(np.nan_to_num(att_g - att_c)).max() <= 1e-5, scale
+        assert np.abs(np.nan_to_num(em_g - em_c)).max() <= 1e-5, scale
+
+
+@pytest.mark.parametrize("sid", [0, 3, 8, 100])
+def test_textures_on_made_up_hit_records(sid):
+    """Texture::value (src/texture.rs:40-73) through Material::scatter / emitted for every material of the scene, on hit records
+    no traversal produces: (u, v) on and beyond [0, 1] (clamped by the image lookup), points on whole numbers (cell borders of the
+    checker and of the noise lattice), negative coordinates, points 3e9 and 1e15 away (floor(p) as i32 saturates)."""
+    gpu, cpu = rt.Scene.builtin(sid, 16, 16, max_depth=4), ob.OracleScene.builtin(sid, 16, 16, max_depth=4)
+    n_mat = len(cpu.materials())
+    rng = np.random.default_rng(sid)
+    edge = np.array([-0.5, 0.0, 1e-9, 0.25, 0.5, 0.999999, 1.0, 1.5], np.float32)
+    for spread in (1.0, 50.0, 5e3, 3e9, 1e15):
+        n = 3000
+        hits, rays = np.zeros(n, _abi.hit_dtype()), np.zeros(n, _abi.ray_dtype())
+        hits["hit"], hits["t"], hits["front_face"] = 1, 1.0, 1
+        hits["point"] = (rng.normal(size=(n, 3)) * spread).astype(np.float32)
+        hits["point"][: n // 10] = np.round(hits["point"][: n // 10])
+        nrm = rng.normal(size=(n, 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        hits["normal"] = nrm.astype(np.float32)
+        hits["u"], hits["v"] = rng.choice(edge, n), rng.choice(edge, n)
+        hits["material"] = rng.integers(0, n_mat, n)
+        rays["direction"] = -nrm.astype(np.float32)
+        rays["rng_pixel"], rays["rng_sample"] = np.arange(n), 1
+        rays["tmin"], rays["tmax"] = 0.001, np.inf
+        _, att_c, em_c = cpu.shade(rays, hits, seed=1)
+        _, att_g, em_g = gpu.shade(rays, hits, seed=1)
+        assert np.array_equal(np.isnan(att_g), np.isnan(att_c)), spread
+        assert np.abs(np.nan_to_num(att_g - att_c)).max() <= 1e-4 and np.abs(np.nan_to_num(em_g - em_c)).max() <= 1e-4, spread
+
+
 @pytest.mark.parametrize("tail_start", [1 << 20, -1], ids=["per_bounce_kernels", "default_schedule"])
 @pytest.mark.parametrize("sid", GOLDEN_SCENES)
 def test_image_with_shared_random_numbers_matches_golden(sid, tail_start):
