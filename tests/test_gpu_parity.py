@@ -37,7 +37,7 @@ def enc(acc, n):
     return np.sqrt(np.clip(acc[..., :3] / n, 0.0, 1.0))
 
 
-def check_hits(gpu, cpu, min_agree=0.999, normal_tol=1e-4):
+def check_hits(gpu, cpu, min_agree=0.999, normal_tol=1e-4, uv_tol=1e-4):
     agree = gpu["hit"] == cpu["hit"]
     assert agree.mean() >= min_agree, f"hit/miss agreement {agree.mean():.5f}"
     both = (gpu["hit"] == 1) & (cpu["hit"] == 1)
@@ -58,7 +58,7 @@ def check_hits(gpu, cpu, min_agree=0.999, normal_tol=1e-4):
         assert np.array_equal(np.isnan(g[f][not_medium]), np.isnan(c[f][not_medium]))
     uv_err = np.nan_to_num(np.maximum(np.abs(g["u"] - c["u"]), np.abs(g["v"] - c["v"])))[not_medium]
     seam = np.nan_to_num(np.minimum(c["u"], 1 - c["u"]))[not_medium] < 1e-3
-    assert uv_err[~seam].max(initial=0.0) <= 1e-4
+    assert uv_err[~seam].max(initial=0.0) <= uv_tol
     return float((g["t"] == c["t"]).mean()) if len(g) else 1.0
 
 
@@ -278,7 +278,7 @@ def _random_scene(s, rng):
     return s
 
 
-@pytest.mark.parametrize("scene_seed", [42, 7, 2026])
+@pytest.mark.parametrize("scene_seed", [42, 7, 2026, 1, 3, 19])
 def test_random_scene_through_the_builder_api(scene_seed):
     gpu = _random_scene(rt.Scene(), np.random.default_rng(scene_seed))
     cpu = _random_scene(ob.OracleScene(), np.random.default_rng(scene_seed))
@@ -292,12 +292,14 @@ def test_random_scene_through_the_builder_api(scene_seed):
     rays["rng_pixel"], rays["rng_sample"], rays["rng_bounce"] = np.arange(n), 3, rng.integers(0, 8, n)
     # Chains of Move/RotateY deeper than the reference's Move{RotateY{..}} are composed into one
     # placement, which rounds differently from applying them one by one; on grazing hits of small
-    # spheres that shows up in the normal ((p - c) / r amplifies it), hence the wider bound here.
+    # spheres that shows up in the normal ((p - c) / r amplifies it), and near a sphere's poles in v = acos(-n.y) / pi, whose
+    # slope there is 1 / sqrt(1 - n.y^2) (seeds 1 and 19: normals 2e-5 apart at n.y = -0.997 and -0.9994, v 1e-4 apart), hence
+    # the wider bounds here.
     want = cpu.intersect(rays, seed=99)
-    check_hits(gpu.intersect(rays, seed=99), want, normal_tol=2e-3)
+    check_hits(gpu.intersect(rays, seed=99), want, normal_tol=2e-3, uv_tol=1e-3)
     # the render path's traversal kernels on the same rays (eight bounce numbers: eight launches)
     ext = gpu.extend(rays, seed=99)
-    check_hits(ext, want, normal_tol=2e-3)
+    check_hits(ext, want, normal_tol=2e-3, uv_tol=1e-3)
     _same_records(ext, gpu.intersect(rays, seed=99))
     # camera with defocus blur: the disk draws come before the time draw (src/camera.rs:311-320)
     pix = np.arange(40 * 30, dtype=np.uint32)
@@ -434,6 +436,24 @@ def test_camera_entry_points_and_finalize():
     assert s.samples == 0
     s.empty_render()
     assert s.samples == 1 and s.accumulator()[..., :3].max() < acc[..., :3].max()
+
+
+def test_finalize_of_special_values():
+    """The output mappings (src/camera.rs:95-100,115-118, src/math/vec3.rs:252-259) on sums that are zero, negative, denormal,
+    huge, infinite or NaN, for sample counts up to 4e9 and exposures 0, 1e10 and -1: mean and sqrt bit for bit (NaN where the
+    restatement has NaN), the packed bytes (`as u32` saturates, NaN becomes 0) to one step."""
+    s = rt.Scene.builtin(6, 16, 16)
+    special = np.array([0.0, -0.0, 1e-45, 1e-38, 1e-10, 0.25, 1.0, 3.0, 255.0, 65536.0, 1e10, 1e38, 3.4e38, np.inf, -np.inf, np.nan,
+                        -1.0, -1e-30, -1e30], np.float32)
+    acc = np.random.default_rng(0).choice(special, (64, 64, 4)).astype(np.float32)
+    for samples in (1, 3, 4096, 4000000000):
+        for mode in (_abi.FINALIZE_MEAN, _abi.FINALIZE_SQRT):
+            assert np.array_equal(s.finalize(acc, samples, mode), ob.finalize(acc, samples, mode), equal_nan=True)
+        for exposure in (1.0, 0.0, 1e10, -1.0):
+            g = s.finalize(acc, samples, _abi.FINALIZE_TONEMAP_RGBA, exposure=exposure)
+            c = ob.finalize(acc, samples, _abi.FINALIZE_TONEMAP_RGBA, exposure=exposure)
+            shifts = np.array([0, 8, 16, 24])
+            assert np.abs(((g[..., None] >> shifts) & 255).astype(int) - ((c[..., None] >> shifts) & 255).astype(int)).max() <= 1
 
 
 def test_counters_agree_with_oracle():
