@@ -690,6 +690,29 @@ def test_very_long_and_very_short_direction_vectors(sid):
                 assert np.nanmax(rel, initial=0.0) <= 1e-6, scale
 
 
+@pytest.mark.parametrize("sid,extent", [(0, 12.0), (1, 12.0), (3, 8.0), (6, 600.0), (7, 600.0), (8, 700.0), (101, 12.0)])
+def test_random_rays_from_inside_the_scenes(sid, extent):
+    """Rays no camera casts: origins anywhere in the scene's extent (inside spheres, inside media, behind walls), directions of
+    any length, five bounce numbers.  Hit or miss must be the restatement's for every ray, t bit-equal where no leaf sits
+    behind a Move and no medium is involved."""
+    gpu, cpu = rt.Scene.builtin(sid, 16, 16, max_depth=4), ob.OracleScene.builtin(sid, 16, 16, max_depth=4)
+    rng = np.random.default_rng(1000 + sid)
+    n = 12000
+    rays = np.zeros(n, _abi.ray_dtype())
+    rays["origin"] = rng.uniform(-0.2 * extent, extent, (n, 3))
+    rays["direction"] = rng.normal(size=(n, 3)) * rng.uniform(0.05, 20, (n, 1))
+    rays["time"] = rng.uniform(0, 1, n)
+    rays["tmin"], rays["tmax"] = 0.001, np.inf
+    rays["rng_pixel"], rays["rng_sample"], rays["rng_bounce"] = np.arange(n) % 4096, 1 + np.arange(n) // 4096, rng.integers(0, 5, n)
+    want = cpu.intersect(rays, seed=7)
+    a, b = gpu.intersect(rays, seed=7), gpu.extend(rays, seed=7)
+    _same_records(a, b)
+    assert np.array_equal(a["hit"], want["hit"])
+    exact = check_hits(a, want, min_agree=0.9999)
+    assert exact == 1.0 if sid in (0, 3) else exact >= 0.9
+    assert 0.3 < want["hit"].mean()
+
+
 def test_extend_kernel_rejects_rays_the_render_path_never_casts():
     s = rt.Scene.builtin(6, 16, 16)
     rays = s.primary_rays(np.arange(4, dtype=np.uint32), 1)
