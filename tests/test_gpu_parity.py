@@ -331,6 +331,23 @@ def test_edge_cases_empty_single_and_ragged():
     assert s1.intersect(np.zeros(0, _abi.ray_dtype())).shape == (0,)
 
 
+@pytest.mark.parametrize("sid", [0, 6, 8])
+def test_odd_image_sizes_and_path_depths(sid):
+    """One pixel, one column, one row, sizes that are no multiple of anything; max_depth 0 (every path is black,
+    src/camera.rs:339-342), 1, 2 and 60: shared random numbers, the accumulator against the restatement's."""
+    for (w, h) in ((1, 1), (1, 7), (64, 1), (3, 129), (65, 63)):
+        for depth in (0, 1, 2, 60):
+            gpu, cpu = rt.Scene.builtin(sid, w, h, max_depth=depth), ob.OracleScene.builtin(sid, w, h, max_depth=depth)
+            gpu.set_seed(11)
+            gpu.render_samples(3)
+            got, want = gpu.accumulator(), cpu.render(3, seed=11)
+            assert got.shape == want.shape and np.isfinite(got).all()
+            close = np.all(np.abs(got[..., :3] - want[..., :3]) <= 1e-4 * np.maximum(1.0, np.abs(want[..., :3])), axis=-1)
+            assert close.mean() >= 0.97, (w, h, depth, close.mean())
+            if depth == 0:
+                assert not got[..., :3].any()
+
+
 def test_render_is_independent_of_batching_and_sample_splits():
     a = rt.Scene.builtin(8, 64, 40)
     a.set_seed(3)
