@@ -385,6 +385,32 @@ def test_render_is_independent_of_batching_and_sample_splits():
     a._check(a.amd.rt_host_buffer_destroy(a.ctx, p))
 
 
+def test_contexts_of_several_host_threads_render_side_by_side():
+    """A context belongs to one host thread (as `&mut Camera` does in the reference); several threads, each with a context and a
+    scene of its own on the same GPU, render at the same time and get the images they get alone."""
+    import threading
+    cases = [(8, 256, 192, 4), (6, 300, 200, 3), (0, 320, 180, 5), (3, 200, 200, 2)]
+
+    def job(k, out):
+        sid, w, h, spp = cases[k]
+        s = rt.Scene.builtin(sid, w, h, max_depth=12)
+        s.set_seed(k)
+        for _ in range(3):
+            s.render_samples(spp)
+        out[k] = s.accumulator().copy()
+
+    alone, together = {}, {}
+    for k in range(len(cases)):
+        job(k, alone)
+    threads = [threading.Thread(target=job, args=(k, together)) for k in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(len(cases)):
+        assert np.array_equal(alone[k], together[k]), k
+
+
 def test_two_pipelines_give_the_same_image_as_one():
     """A render large enough to be split over the two internal streams (>= 4 Mi paths) equals the
     one-stream render bit for bit, also when the sample count does not divide evenly."""
