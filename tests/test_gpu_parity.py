@@ -313,6 +313,53 @@ def test_random_scene_through_the_builder_api(scene_seed):
     assert np.sqrt(np.mean((enc(got, 8) - enc(want, 8)) ** 2)) <= 2e-3
 
 
+def _degenerate_scene(s):
+    t = [s.tex_solid(0.8, 0.3, 0.3), s.tex_solid(0.3, 0.8, 0.3), s.tex_solid(1, 1, 1)]
+    lam, glass, metal, light = s.lambertian(t[0]), s.dielectric(t[2], 1.5), s.metal(t[1], 0.1), s.diffuse_light(t[2])
+    items = [s.sphere((0, 0, 0), 1.0, glass), s.sphere((0, 0, 0), -0.8, glass),          # hollow glass: negative radius
+             s.sphere((3, 0, 0), 1e-6, lam), s.sphere((-3, 0, 0), 1e-3, metal), s.sphere((0, 5, 0), 0.0, lam),
+             s.sphere((0, -1e6 - 2, 0), 1e6, lam),                                         # a ground of radius 1e6
+             s.quad((2, -1, 2), (1, 0, 0), (0, 1, 0), light),
+             s.quad((-2, -1, 2), (1, 1, 0), (1e-4, 1e-4, 0), lam),                         # almost without area
+             s.quad((0, -1, -3), (1, 0, 0), (2, 0, 0), lam),                               # u parallel to v: no normal
+             s.quad((1, -1, -3), (0, 0, 0), (0, 1, 0), lam),                               # u = 0
+             s.moving_sphere((0, 3, 0), (0, 3, 0), 0.5, metal),                            # "moving" by nothing
+             s.move(s.rotate_y(s.sphere((0, 0, 0), -0.6, glass), 30.0), (2, 2, -1)),
+             s.medium(s.sphere((-2, 2, 0), 1.0, lam), 2.0, t[1]),
+             s.medium(s.sphere((-2, 2, 0), 0.5, lam), 5.0, t[0]),                          # a medium inside a medium
+             s.medium(s.sphere((4, 2, 0), -1.0, lam), 1.0, t[2])]                          # a medium in a negative-radius sphere
+    s.set_world(s.bvh(items))
+    s.camera((0, 1, -12), 32, 24, max_depth=8, vfov=40.0, background=(0.5, 0.6, 0.7), yaw=90.0)
+    return s
+
+
+def test_degenerate_primitives():
+    """Radii that are negative (src/hittable.rs:262-288 divides the normal by the radius: the book's hollow glass), zero, tiny
+    and huge; quads without area or without a normal (unit(0) = NaN: never hit); media inside media and inside a negative-radius
+    sphere.  Per ray and as an image, against the restatement."""
+    gpu, cpu = _degenerate_scene(rt.Scene()), _degenerate_scene(ob.OracleScene())
+    rng = np.random.default_rng(5)
+    n = 40000
+    rays = np.zeros(n, _abi.ray_dtype())
+    rays["origin"] = rng.uniform(-6, 6, (n, 3))
+    rays["origin"][: n // 4] = rng.normal(size=(n // 4, 3)) * 0.5     # many from inside the glass shells
+    rays["direction"] = rng.normal(size=(n, 3)) * rng.uniform(0.1, 5, (n, 1))
+    rays["time"] = rng.uniform(0, 1, n)
+    rays["tmin"], rays["tmax"] = 0.001, np.inf
+    rays["rng_pixel"], rays["rng_sample"] = np.arange(n) % 4096, 1 + np.arange(n) // 4096
+    want = cpu.intersect(rays, seed=3)
+    a, b = gpu.intersect(rays, seed=3), gpu.extend(rays, seed=3)
+    _same_records(a, b)
+    assert np.array_equal(a["hit"], want["hit"])
+    assert check_hits(a, want, min_agree=0.9995) >= 0.99
+    gpu.set_seed(9)
+    gpu.render_samples(4)
+    got, ref = gpu.accumulator(), cpu.render(4, seed=9)
+    assert np.isfinite(got).all() and np.isfinite(ref).all()
+    close = np.all(np.abs(got[..., :3] - ref[..., :3]) <= 1e-4 * np.maximum(1.0, np.abs(ref[..., :3])), axis=-1)
+    assert close.mean() >= 0.99
+
+
 def test_edge_cases_empty_single_and_ragged():
     # empty world: every path returns the background (src/camera.rs:347-349)
     s = rt.Scene()
