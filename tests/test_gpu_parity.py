@@ -313,6 +313,34 @@ def test_random_scene_through_the_builder_api(scene_seed):
     assert np.sqrt(np.mean((enc(got, 8) - enc(want, 8)) ** 2)) <= 2e-3
 
 
+def test_random_and_extreme_cameras():
+    """RaytracingCamera::new + get_ray (src/camera.rs:222-266,311-320) for forty random cameras (fields of view from 0.01 to
+    179.99 degrees, up vectors of any length, focus distances from 1e-6 to 1e6, defocus up to 179 degrees, images down to one
+    pixel) and three broken ones (looking along vup, fields of view of 0 and 180 degrees): the same rays bit for bit, NaN where
+    the restatement has NaN."""
+    rng = np.random.default_rng(0)
+    cases = []
+    for _ in range(40):
+        cases.append(dict(pos=tuple(rng.uniform(-1e3, 1e3, 3)), width=int(rng.integers(1, 70)), height=int(rng.integers(1, 50)),
+                          vfov=float(rng.choice([0.01, 1.0, 20.0, 40.0, 90.0, 150.0, 179.0, 179.99])),
+                          vup=tuple(rng.normal(size=3) * rng.choice([1e-3, 1.0, 1e3])),
+                          defocus_angle=float(rng.choice([0.0, 0.0, 1e-3, 0.6, 10.0, 179.0])), focus_dist=float(rng.choice([1e-6, 0.1, 10.0, 1e6])),
+                          pitch=float(rng.choice([0.0, -89.9, 89.9, 15.0, -15.0, 45.0])), yaw=float(rng.uniform(-720, 720))))
+    for pitch, vfov in ((90.0, 40.0), (0.0, 0.0), (0.0, 180.0)):
+        cases.append(dict(pos=(0, 0, 0), width=3, height=3, vfov=vfov, vup=(0, 1, 0), defocus_angle=0.0, focus_dist=10.0, pitch=pitch, yaw=0.0))
+    for c in cases:
+        g, o = rt.Scene(), ob.OracleScene()
+        for s_ in (g, o):
+            s_.set_world(s_.bvh([s_.sphere((0, 0, 0), 1.0, s_.lambertian(s_.tex_solid(0.5, 0.5, 0.5)))]))
+            s_.camera(c["pos"], c["width"], c["height"], max_depth=3, vfov=c["vfov"], vup=c["vup"], defocus_angle=c["defocus_angle"],
+                      focus_dist=c["focus_dist"], background=(1, 1, 1), pitch=c["pitch"], yaw=c["yaw"])
+        pix = np.arange(c["width"] * c["height"], dtype=np.uint32)
+        for sample in (1, 77):
+            a, b = g.primary_rays(pix, sample, seed=4), o.primary_rays(pix, sample, seed=4)
+            for f in ("origin", "direction", "time"):
+                assert np.array_equal(a[f], b[f], equal_nan=True), (c, f)
+
+
 def _degenerate_scene(s):
     t = [s.tex_solid(0.8, 0.3, 0.3), s.tex_solid(0.3, 0.8, 0.3), s.tex_solid(1, 1, 1)]
     lam, glass, metal, light = s.lambertian(t[0]), s.dielectric(t[2], 1.5), s.metal(t[1], 0.1), s.diffuse_light(t[2])
