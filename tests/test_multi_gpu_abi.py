@@ -87,9 +87,28 @@ def _check_multi(devices):
     buf.free()
 
 
-@pytest.mark.parametrize("n_ctx", [1, 2, 3])
+@pytest.mark.parametrize("n_ctx", [1, 2, 3, 8])   # eight: more shares than the six samples of the second call
 def test_multi_entry_point_with_several_contexts_on_one_gpu(n_ctx):
     _check_multi([0] * n_ctx)
+
+
+def test_multi_entry_point_with_more_shares_than_rows():
+    """Five contexts, an image of three rows, one sample: two shares of the rows and four shares of the samples are empty."""
+    w, h = 33, 3
+    scenes = [rt.Scene.builtin(6, w, h, max_depth=5) for _ in range(5)]
+    head, others = scenes[0], scenes[1:]
+    alone = rt.Scene.builtin(6, w, h, max_depth=5)
+    ref = DeviceBuffer(alone, (h, w, 4))
+    alone.render_accumulate_device(ref.ptr, 1, 2, seed=SEED)
+    want = ref.get()
+    ref.free()
+    for split in (_abi.SPLIT_ROWS, _abi.SPLIT_SAMPLES):
+        buf = DeviceBuffer(head, (h, w, 4))
+        head.render_accumulate_multi(others, buf.ptr, 1, 1, seed=SEED, split=split)
+        head.render_accumulate_multi(others, buf.ptr, 2, 1, seed=SEED, split=split)
+        head.synchronize()
+        assert np.array_equal(buf.get(), want), split     # one sample per call: a single share holds it, nothing is re-associated
+        buf.free()
 
 
 def test_multi_entry_point_across_gpus():
