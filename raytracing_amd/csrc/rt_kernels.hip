@@ -693,22 +693,31 @@ RT_D ShadeRec shade_rec_of_leaf(const DScene& sc, uint4 m0, uint4 m1) {
     return r;
 }
 
+// Rust's `as i32` / `as u32`: saturating, NaN becomes 0 (a C cast of such values is undefined)
+RT_D int rust_as_i32(float f) { return f != f ? 0 : (f >= 2147483648.0f ? 2147483647 : (f <= -2147483648.0f ? (-2147483647 - 1) : (int)f)); }
+RT_D uint32_t rust_as_u32(float f) { return !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)f); }
+// is_even of Texture::Checker (src/texture.rs:46-48): the floor of all FOUR lanes of inv_scale * p is summed, and the fourth
+// lane is inv_scale * 0 - zero, except for a checker of scale 0 (inv_scale = inf), where it is NaN and the sum with it.
+RT_D bool checker_is_even(float inv_scale, float3 p) {
+    const float sum = ((floorf(inv_scale * p.x) + floorf(inv_scale * p.y)) + floorf(inv_scale * p.z)) + floorf(inv_scale * 0.0f);
+    return (rust_as_i32(sum) % 2) == 0;
+}
+
 // Texture::value (src/texture.rs:40-73) for textures that are not a plain colour
 RT_D float3 texture_value_slow(const DScene& sc, uint32_t tex_id, HitGeom& g, PerlinLds lds_perlin) {
     DTexture t = sc.textures[tex_id];
     for (int guard = 0; guard < 16 && t.kind == RT_TEX_CHECKER; ++guard) {
-        float sum = floorf(t.scale * g.p.x) + floorf(t.scale * g.p.y) + floorf(t.scale * g.p.z);
-        bool is_even = ((int)sum % 2) == 0;
-        t = sc.textures[is_even ? t.even : t.odd];
+        t = sc.textures[checker_is_even(t.scale, g.p) ? t.even : t.odd];
     }
     if (t.kind == RT_TEX_SOLID) return f3(t.r, t.g, t.b);
     if (t.kind == RT_TEX_IMAGE) {
         ensure_uv(g);
         DImage im = sc.images[t.image];
-        float u = fminf(fmaxf(g.u, 0.0f), 1.0f);
-        float v = 1.0f - fminf(fmaxf(g.v, 0.0f), 1.0f);
-        uint32_t i = (uint32_t)(u * (float)(im.width - 1));
-        uint32_t j = (uint32_t)(v * (float)(im.height - 1));
+        // f32::clamp hands a NaN through (v = acos(-n.y) / pi is NaN where rounding leaves |n.y| a hair above 1), `as u32` turns it into 0
+        float u = g.u < 0.0f ? 0.0f : (g.u > 1.0f ? 1.0f : g.u);
+        float v = 1.0f - (g.v < 0.0f ? 0.0f : (g.v > 1.0f ? 1.0f : g.v));
+        uint32_t i = rust_as_u32(u * (float)(im.width - 1));
+        uint32_t j = rust_as_u32(v * (float)(im.height - 1));
         size_t at = (size_t)j * im.width + i;
         float3 px;
         if (im.format == RT_IMAGE_RGB8) {
@@ -1170,8 +1179,7 @@ RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, ui
     ShadeRec rec = shade_rec_of_leaf(sc, m0, m1);
     if (PLAIN_CHECKERS && ref_class(h.y) == CLS_CHECKER) {  // Texture::Checker over two plain colours (src/texture.rs:45-55)
         const DChecker ck = sc.checkers[m0.x];
-        const float sum = floorf(ck.scale * g.p.x) + floorf(ck.scale * g.p.y) + floorf(ck.scale * g.p.z);
-        const bool is_even = ((int)sum % 2) == 0;
+        const bool is_even = checker_is_even(ck.scale, g.p);
         rec.colour = is_even ? f3(ck.even[0], ck.even[1], ck.even[2]) : f3(ck.odd[0], ck.odd[1], ck.odd[2]);
         rec.tex_kind = RT_TEX_SOLID;  // the texture has been evaluated
     }
@@ -1481,9 +1489,7 @@ __global__ __launch_bounds__(256) void k_add_buffers(float4* __restrict__ acc, c
 // Colour::to_rgba (src/math/vec3.rs:252-259)
 RT_D uint32_t to_rgba(float3 c) {
     float r = sqrtf(c.x) * 255.999f, g = sqrtf(c.y) * 255.999f, bl = sqrtf(c.z) * 255.999f;
-    uint32_t ri = r > 0.0f ? (uint32_t)fminf(r, 4294967040.0f) : 0u;
-    uint32_t gi = g > 0.0f ? (uint32_t)fminf(g, 4294967040.0f) : 0u;
-    uint32_t bi = bl > 0.0f ? (uint32_t)fminf(bl, 4294967040.0f) : 0u;
+    uint32_t ri = rust_as_u32(r), gi = rust_as_u32(g), bi = rust_as_u32(bl);
     return (ri << 0) | (gi << 8) | (bi << 16);
 }
 

@@ -148,6 +148,57 @@ def test_textures_on_made_up_hit_records(sid):
         assert np.abs(np.nan_to_num(att_g - att_c)).max() <= 1e-4 and np.abs(np.nan_to_num(em_g - em_c)).max() <= 1e-4, spread
 
 
+def _texture_zoo(s):
+    rng = np.random.default_rng(1)
+    texs = [s.tex_image(rng.integers(0, 256, (1, 1, 3), dtype=np.uint8)), s.tex_image(rng.integers(0, 256, (1, 7, 3), dtype=np.uint8)),
+            s.tex_image(rng.integers(0, 256, (6, 1, 3), dtype=np.uint8)), s.tex_image(rng.integers(0, 256, (64, 33, 3), dtype=np.uint8)),
+            s.tex_image((rng.normal(size=(4, 5, 3)) * 3).astype(np.float32)),
+            s.tex_image(np.array([[[np.nan, np.inf, -np.inf], [1e30, -1e30, 1e-40]]], np.float32))]
+    a, b = s.tex_solid(0.1, 0.2, 0.3), s.tex_solid(0.9, 0.8, 0.7)
+    for scale in (0.0, -1.5, 1e-20, 1e20, 0.64, float("inf")):
+        texs.append(s.tex_checker(scale, a, b))
+    texs.append(s.tex_checker(0.5, texs[3], texs[-2]))
+    texs.append(s.tex_checker(2.0, texs[-1], texs[4]))
+    for scale in (0.0, -3.0, 1e10):
+        texs.append(s.tex_noise(s.perlin((1, 2, 3, 4), 17), scale))
+    mats = [s.lambertian(t) for t in texs] + [s.diffuse_light(t) for t in texs] + [s.isotropic(texs[3]), s.metal(texs[4], 0.3)]
+    s.set_world(s.bvh([s.sphere((i, 0, 0), 0.4, m) for i, m in enumerate(mats)]))
+    s.camera((0, 0, -10), 8, 8, max_depth=3, yaw=90.0)
+    return s
+
+
+def test_image_checker_and_noise_textures_on_their_edges():
+    """Images of one texel, one row, one column, u8 and f32 with values beyond [0, 1], infinite and NaN; checkers of scale 0
+    (inv_scale = inf: the fourth SIMD lane, inf * 0 = NaN, turns the summed floors into NaN and `as i32` into 0), negative, tiny,
+    huge and infinite scale, checkers of checkers of images; noise scaled by 0, -3 and 1e10.  (u, v) from -1e30 to 1e30, +-0,
+    +-inf and NaN: f32::clamp hands NaN through and `as u32` makes it texel 0 (src/texture.rs:45-66) - v IS NaN at a sphere's pole
+    when rounding leaves |n.y| above 1."""
+    gpu, cpu = _texture_zoo(rt.Scene()), _texture_zoo(ob.OracleScene())
+    n_mat = len(cpu.materials())
+    rng = np.random.default_rng(2)
+    edge = np.array([-1e30, -0.5, -0.0, 0.0, 1e-9, 0.25, 0.5, 0.999999, 1.0, 1.0000001, 1.5, 1e30, np.inf, -np.inf, np.nan], np.float32)
+    for spread in (1.0, 30.0, 1e7):
+        n = 6000
+        hits, rays = np.zeros(n, _abi.hit_dtype()), np.zeros(n, _abi.ray_dtype())
+        hits["hit"], hits["t"], hits["front_face"] = 1, 1.0, 1
+        hits["point"] = (rng.normal(size=(n, 3)) * spread).astype(np.float32)
+        hits["point"][: n // 10] = np.round(hits["point"][: n // 10])
+        nrm = rng.normal(size=(n, 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        hits["normal"] = nrm.astype(np.float32)
+        hits["u"], hits["v"] = rng.choice(edge, n), rng.choice(edge, n)
+        hits["material"] = rng.integers(0, n_mat, n)
+        rays["direction"] = -nrm.astype(np.float32)
+        rays["rng_pixel"], rays["rng_sample"] = np.arange(n), 1
+        rays["tmin"], rays["tmax"] = 0.001, np.inf
+        _, att_c, em_c = cpu.shade(rays, hits, seed=1)
+        _, att_g, em_g = gpu.shade(rays, hits, seed=1)
+        with np.errstate(all="ignore"):
+            for g, c in ((att_g, att_c), (em_g, em_c)):
+                same = (g == c) | (np.isnan(g) & np.isnan(c)) | (np.abs(g - c) <= 1e-4 * np.maximum(1.0, np.abs(c)))
+                assert same.all(), (spread, hits["material"][~same.all(axis=1)][:8])
+
+
 @pytest.mark.parametrize("tail_start", [1 << 20, -1], ids=["per_bounce_kernels", "default_schedule"])
 @pytest.mark.parametrize("sid", GOLDEN_SCENES)
 def test_image_with_shared_random_numbers_matches_golden(sid, tail_start):
