@@ -392,6 +392,101 @@ def test_random_and_extreme_cameras():
                 assert np.array_equal(a[f], b[f], equal_nan=True), (c, f)
 
 
+def _pole_scene(s):
+    m = s.lambertian(s.tex_solid(0.5, 0.5, 0.5))
+    centres = [(0, 0, 0), (4, 0, 0), (0, 4, 0), (0, 0, 4), (-4, 1, 2), (8, 8, 8)]
+    radii = [1.0, 0.5, 3.0 / 7.0, 1.25, 0.1, 2.0]
+    items = [s.sphere(c, r, m) for c, r in zip(centres[:3], radii[:3])]
+    items.append(s.moving_sphere(centres[3], centres[3], radii[3], m))
+    items.append(s.move(s.rotate_y(s.sphere((0, 0, 0), radii[4], m), 37.0), centres[4]))
+    items.append(s.move(s.rotate_y(s.sphere((0, 0, 0), radii[5], m), 90.0), centres[5]))
+    s.set_world(s.bvh(items))
+    s.camera((0, 0, -20), 8, 8, max_depth=3, yaw=90.0)
+    return centres, radii
+
+
+def test_rays_aimed_at_the_poles_and_the_seam_of_spheres():
+    """get_sphere_uv (src/hittable.rs:341-352) where it is least well behaved: along the six axes through still, moving and placed
+    spheres, exactly and a hair off.  v = acos(-n.y) / pi is NaN when rounding leaves |n.y| above 1 (147 of these 1728 rays): the
+    same rays must get NaN on both sides; u is compared across its wrap."""
+    gpu, cpu = rt.Scene(), ob.OracleScene()
+    centres, radii = _pole_scene(gpu)
+    _pole_scene(cpu)
+    rng = np.random.default_rng(0)
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float64)
+    o, d = [], []
+    for c, r in zip(centres, radii):
+        for a in axes:
+            for dist in (3.0, 7.5, 1.0 + r):
+                for eps in (0.0, 1e-7, 1e-5, 1e-3):
+                    for _ in range(4):
+                        o.append(np.array(c, np.float64) + a * (r + dist) + rng.normal(size=3) * eps * r)
+                        d.append(-a * rng.choice([1.0, 0.3, 4.0]))
+    n = len(o)
+    rays = np.zeros(n, _abi.ray_dtype())
+    rays["origin"], rays["direction"] = np.array(o, np.float32), np.array(d, np.float32)
+    rays["time"] = rng.uniform(0, 1, n)
+    rays["tmin"], rays["tmax"] = 0.001, np.inf
+    rays["rng_pixel"], rays["rng_sample"] = np.arange(n), 1
+    want = cpu.intersect(rays)
+    assert want["hit"].all() and np.isnan(want["v"]).sum() > 50
+    for got in (gpu.intersect(rays), gpu.extend(rays)):
+        assert np.array_equal(got["hit"], want["hit"]) and np.array_equal(got["prim_id"], want["prim_id"]) and np.array_equal(got["t"], want["t"])
+        assert np.array_equal(np.isnan(got["u"]), np.isnan(want["u"])) and np.array_equal(np.isnan(got["v"]), np.isnan(want["v"]))
+        with np.errstate(all="ignore"):
+            du = np.abs(got["u"] - want["u"])
+            assert np.nan_to_num(np.minimum(du, 1 - du)).max() <= 1e-4 and np.nan_to_num(np.abs(got["v"] - want["v"])).max() <= 1e-4
+
+
+_EDGE_QUADS = [((0, 0, 0), (4, 0, 0), (0, 2, 0)), ((8, 0, 0), (0, 0, 4), (0, 4, 0)), ((0, 8, 0), (2, 0, 0), (0, 0, 2)), ((-8, 0, 0), (3, 1, 0), (-1, 3, 0)),
+               ((0, -8, 1), (1, 0, 1), (1, 2, -1)), ((16, 16, 16), (0.5, 0, 0), (0, 0.25, 0))]
+
+
+def _edge_scene(s):
+    m = s.lambertian(s.tex_solid(0.5, 0.5, 0.5))
+    items = [s.quad(q, u, v, m) for q, u, v in _EDGE_QUADS]
+    items.append(s.move(s.rotate_y(s.quad((0, 0, 0), (2, 0, 0), (0, 2, 0), m), 30.0), (-16, 0, 0)))
+    items.append(s.move(s.rotate_y(s.box((0, 0, 0), (1, 2, 3), m), 90.0), (0, 0, -16)))
+    s.set_world(s.bvh(items))
+    s.camera((0, 0, -40), 8, 8, max_depth=3, yaw=90.0)
+    return s
+
+
+def test_rays_aimed_at_corners_and_edges_of_quads():
+    """Quad::hit (src/hittable.rs:372-398) accepts 0 <= alpha, beta <= 1 and tmin <= t <= tmax, bounds included.  Rays aimed at
+    corners, edges and a hair inside / outside them (1e-7 of the edge), from 1, 2 and 8 units away and from tmin and a hair
+    around it, at two oblique angles: hit or miss, t, alpha and beta must be the restatement's bit for bit."""
+    gpu, cpu = _edge_scene(rt.Scene()), _edge_scene(ob.OracleScene())
+    steps = (0.0, 0.5, 1.0, 0.25, 1e-7, 1 - 1e-7, -1e-7, 1 + 1e-7)
+    o, d = [], []
+    for q, u, v in _EDGE_QUADS:
+        q, u, v = (np.array(x, np.float64) for x in (q, u, v))
+        nrm = np.cross(u, v)
+        nrm /= np.linalg.norm(nrm)
+        uh, vh = u / np.linalg.norm(u), v / np.linalg.norm(v)
+        for a in steps:
+            for b in steps:
+                target = q + a * u + b * v
+                for side in (1.0, -1.0):
+                    for dist in (1.0, 2.0, 8.0, 0.001, 0.0009999, 0.0010001):
+                        o.append(target + side * dist * nrm + dist * (uh - 3.0 * vh) + dist * np.array([0.5, 0.25, 0.125]))
+                        d.append(target - o[-1])                 # t = 1
+                        o.append(target + side * 2.0 * dist * nrm + dist * (0.3 * vh - uh) + dist * np.array([0.125, 0.5, 0.25]))
+                        d.append((target - o[-1]) * 0.5)         # t = 2
+    n = len(o)
+    rays = np.zeros(n, _abi.ray_dtype())
+    rays["origin"], rays["direction"] = np.array(o, np.float32), np.array(d, np.float32)
+    rays["tmin"], rays["tmax"] = 0.001, np.inf
+    rays["rng_pixel"], rays["rng_sample"] = np.arange(n), 1
+    assert (rays["direction"] != 0).all()
+    want = cpu.intersect(rays)
+    assert 0.2 < want["hit"].mean() < 0.9
+    for got in (gpu.intersect(rays), gpu.extend(rays)):
+        assert np.array_equal(got["hit"], want["hit"]) and np.array_equal(got["prim_id"], want["prim_id"])
+        for f in ("t", "u", "v"):
+            assert np.array_equal(got[f], want[f]), f
+
+
 def _degenerate_scene(s):
     t = [s.tex_solid(0.8, 0.3, 0.3), s.tex_solid(0.3, 0.8, 0.3), s.tex_solid(1, 1, 1)]
     lam, glass, metal, light = s.lambertian(t[0]), s.dielectric(t[2], 1.5), s.metal(t[1], 0.1), s.diffuse_light(t[2])
