@@ -148,6 +148,61 @@ def test_textures_on_made_up_hit_records(sid):
         assert np.abs(np.nan_to_num(att_g - att_c)).max() <= 1e-4 and np.abs(np.nan_to_num(em_g - em_c)).max() <= 1e-4, spread
 
 
+def _material_zoo(s):
+    t = s.tex_solid(0.7, 0.6, 0.5)
+    mats = [s.lambertian(t), s.isotropic(t), s.diffuse_light(t)]
+    mats += [s.dielectric(t, ri) for ri in (0.0, 1e-10, 0.5, 1.0, 1.5, 2.4, 1e10, -1.5, float("inf"), float("nan"))]
+    mats += [s.metal(t, fuzz) for fuzz in (-1.0, 0.0, 1e-8, 0.5, 1.0, 2.0, float("inf"), float("nan"))]
+    s.set_world(s.bvh([s.sphere((i, 0, 0), 0.4, m) for i, m in enumerate(mats)]))
+    s.camera((0, 0, -10), 8, 8, max_depth=3, yaw=90.0)
+    return s
+
+
+def test_materials_on_made_up_hit_records():
+    """Material::scatter (src/material.rs:65-122) for refraction indices 0, 1e-10 ... 1e10, negative, infinite and NaN, fuzz from -1
+    to infinite and NaN, with incoming directions that are straight on, exactly grazing, a hair inwards, zero, 1e-25 and 1e20
+    long, and normals that are not unit vectors: the same Some / None, the same NaN and infinity pattern, directions to 1e-5 of
+    their size."""
+    gpu, cpu = _material_zoo(rt.Scene()), _material_zoo(ob.OracleScene())
+    n_mat = len(cpu.materials())
+    rng = np.random.default_rng(3)
+    n = 40000
+    hits, rays = np.zeros(n, _abi.hit_dtype()), np.zeros(n, _abi.ray_dtype())
+    hits["hit"], hits["t"] = 1, 1.0
+    hits["point"] = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    kind = rng.integers(0, 8, n)
+    d = rng.normal(size=(n, 3))
+    tang = np.cross(nrm, rng.normal(size=(n, 3)))
+    tang /= np.linalg.norm(tang, axis=1, keepdims=True)
+    d = np.where((kind == 1)[:, None], -nrm, d)
+    d = np.where((kind == 2)[:, None], tang, d)
+    d = np.where((kind == 3)[:, None], tang - 1e-7 * nrm, d)
+    d = np.where((kind == 4)[:, None], 0.0, d)
+    d = np.where((kind == 5)[:, None], d * 1e-25, d)
+    d = np.where((kind == 6)[:, None], d * 1e20, d)
+    nrm = np.where((kind == 7)[:, None], nrm * rng.choice([0.0, 0.5, 3.0, 1e-20], (n, 1)), nrm)
+    hits["normal"] = nrm.astype(np.float32)
+    hits["front_face"] = rng.integers(0, 2, n)
+    hits["u"], hits["v"] = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    hits["material"] = rng.integers(0, n_mat, n)
+    rays["direction"] = d.astype(np.float32)
+    rays["time"] = rng.uniform(0, 1, n)
+    rays["rng_pixel"], rays["rng_sample"], rays["rng_bounce"] = np.arange(n) % 5000, 1 + np.arange(n) // 5000, rng.integers(0, 30, n)
+    rays["tmin"], rays["tmax"] = 0.001, np.inf
+    sc_c, att_c, em_c = cpu.shade(rays, hits, seed=8)
+    sc_g, att_g, em_g = gpu.shade(rays, hits, seed=8)
+    assert np.array_equal(sc_g["tmin"], sc_c["tmin"])
+    assert np.array_equal(np.isnan(sc_g["direction"]), np.isnan(sc_c["direction"])) and np.array_equal(np.isinf(sc_g["direction"]), np.isinf(sc_c["direction"]))
+    with np.errstate(all="ignore"):
+        size = np.maximum(1e-30, np.abs(sc_c["direction"]).max(axis=1, keepdims=True))
+        assert np.nan_to_num(np.abs(sc_g["direction"] - sc_c["direction"]) / size, posinf=0.0).max() <= 1e-5
+    assert np.array_equal(np.isnan(att_g), np.isnan(att_c)) and np.abs(np.nan_to_num(att_g - att_c)).max() <= 1e-5
+    assert np.abs(np.nan_to_num(em_g - em_c)).max() <= 1e-5
+    assert 0.05 < (sc_c["tmin"] == 0).mean() < 0.6     # both outcomes occur
+
+
 def _texture_zoo(s):
     rng = np.random.default_rng(1)
     texs = [s.tex_image(rng.integers(0, 256, (1, 1, 3), dtype=np.uint8)), s.tex_image(rng.integers(0, 256, (1, 7, 3), dtype=np.uint8)),
