@@ -148,6 +148,52 @@ def test_textures_on_made_up_hit_records(sid):
         assert np.abs(np.nan_to_num(att_g - att_c)).max() <= 1e-4 and np.abs(np.nan_to_num(em_g - em_c)).max() <= 1e-4, spread
 
 
+_DENSITIES = (0.0, 1e-12, 0.01, 1.0, 50.0, 1e12, -1.0, float("inf"))
+
+
+def _media_zoo(s):
+    t = s.tex_solid(0.7, 0.6, 0.5)
+    lam = s.lambertian(t)
+    items = []
+    for i, dens in enumerate(_DENSITIES):
+        x = 4.0 * (i - len(_DENSITIES) / 2)
+        items.append(s.medium(s.sphere((x, 0, 0), 1.5, lam), dens, t))
+        items.append(s.medium(s.box((x - 1, 3, -1), (x + 1, 5, 1), lam), dens, t))
+        items.append(s.medium(s.move(s.rotate_y(s.box((-1, -1, -1), (1, 1, 1), lam), 20.0 + 7 * i), (x, -4, 0)), dens, t))
+        items.append(s.medium(s.moving_sphere((x, 0, 5), (x + 0.5, 0.3, 5), 1.2, lam), dens, t))
+    s.set_world(s.bvh(items))
+    s.camera((0, 0, -30), 48, 32, max_depth=6, vfov=50.0, background=(0.7, 0.8, 0.9), yaw=90.0)
+    return s
+
+
+def test_media_of_every_density():
+    """ConstantMedium (src/math/ray.rs:108-163) with densities 0 (-1 / density = -inf: never scatters), 1e-12 ... 1e12, negative
+    and infinite, bounded by a sphere, a box, a placed box and a moving sphere: 60 000 random rays (many from inside) and an
+    image.  The free path uses ln(), so t agrees to 1e-5 rather than bit for bit."""
+    gpu, cpu = _media_zoo(rt.Scene()), _media_zoo(ob.OracleScene())
+    rng = np.random.default_rng(4)
+    n = 60000
+    rays = np.zeros(n, _abi.ray_dtype())
+    rays["origin"] = rng.uniform(-18, 18, (n, 3)) * np.array([1, 0.4, 0.4])
+    rays["direction"] = rng.normal(size=(n, 3)) * rng.uniform(0.05, 10, (n, 1))
+    rays["time"] = rng.uniform(0, 1, n)
+    rays["tmin"], rays["tmax"] = 0.001, np.inf
+    rays["rng_pixel"], rays["rng_sample"], rays["rng_bounce"] = np.arange(n) % 4096, 1 + np.arange(n) // 4096, rng.integers(0, 6, n)
+    want = cpu.intersect(rays, seed=2)
+    a, b = gpu.intersect(rays, seed=2), gpu.extend(rays, seed=2)
+    _same_records(a, b)
+    assert np.array_equal(a["hit"], want["hit"]) and 0.05 < want["hit"].mean() < 0.5
+    hit = want["hit"] == 1
+    assert np.array_equal(a["prim_id"][hit], want["prim_id"][hit])
+    assert (np.abs(a["t"][hit] - want["t"][hit]) <= 1e-5 * np.maximum(1.0, np.abs(want["t"][hit]))).all()
+    gpu.set_seed(6)
+    gpu.render_samples(4)
+    got, ref = gpu.accumulator(), cpu.render(4, seed=6)
+    assert np.isfinite(got).all()
+    close = np.all(np.abs(got[..., :3] - ref[..., :3]) <= 1e-4 * np.maximum(1.0, np.abs(ref[..., :3])), axis=-1)
+    assert close.mean() >= 0.99
+
+
 def _material_zoo(s):
     t = s.tex_solid(0.7, 0.6, 0.5)
     mats = [s.lambertian(t), s.isotropic(t), s.diffuse_light(t)]
