@@ -88,3 +88,26 @@ def test_every_constant_of_the_reference_scene_builders_is_restated(which):
         assert len(theirs) >= 8, scene
         assert strip(theirs - ours) == strip(only_reference), (scene, "missing here", dict(strip(theirs - ours)))
         assert strip(ours - theirs) == strip(only_here), (scene, "not in the reference", dict(strip(ours - theirs)))
+
+
+def test_every_constant_of_the_path_s_formulas_is_restated():
+    """The thresholds and factors of the files on the path (0.001, 1e-8, 0.0001, 255.999, the rotation counts of the generator
+    ...): each occurs in the oracle and in the kernels or the host library.  Not restated as written: the unused global SEED
+    [6, 9, 4, 20] of src/rng.rs:7, and FRACTION_BITS = 52 (src/rng.rs:44), which both sides use as 52 + 1 = 53."""
+    def read(*parts):
+        return open(os.path.join(ROOT, *parts)).read()
+    oracle = literals(read("oracle", "oracle_core.hpp")) + literals(read("oracle", "oracle_capi.cpp"))
+    product = Counter()
+    for parts in (("raytracing_amd", "csrc", "rt_kernels.hip"), ("raytracing_amd", "csrc", "rt_device.h"), ("raytracing_amd", "csrc", "rt_api.hip"),
+                  ("raytracing_amd", "host", "raytracing.cpp"), ("raytracing_amd", "host", "raytracing.hpp")):
+        product += literals(read(*parts))
+    seen = 0
+    for f in ("math/ray.rs", "hittable.rs", "material.rs", "texture.rs", "perlin_noise.rs", "camera.rs", "math/aabb.rs", "math/vec3.rs", "rng.rs"):
+        text = open(os.path.join(os.path.dirname(REFERENCE), f)).read().split("#[cfg(test)]")[0]
+        for value in strip(literals(text)):
+            seen += 1
+            if f == "rng.rs" and value in (20.0, 52.0):
+                continue
+            assert value in oracle, (f, value, "not in the oracle")
+            assert value in product, (f, value, "not in the kernels or the host library")
+    assert seen >= 25
