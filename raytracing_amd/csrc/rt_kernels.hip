@@ -619,9 +619,17 @@ RT_D float perlin_noise(const Tables& pn, float3 p) {
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     float u = p.x - fx, v = p.y - fy, w = p.z - fz;
     uint32_t i[2], j[2], k[2];
-    lattice_bytes(fx, i);
-    lattice_bytes(fy, j);
-    lattice_bytes(fz, k);
+    const bool far_out = !(fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)) < 2147483648.0f);   // or NaN
+    if (__builtin_amdgcn_ballot_w64(far_out) == 0ull) {  // no lane of the wave is: the plain 32-bit conversion is in range
+        const int ii = (int)fx, jj = (int)fy, kk = (int)fz;
+        i[0] = (uint32_t)ii & 255u; i[1] = (uint32_t)(ii + 1) & 255u;
+        j[0] = (uint32_t)jj & 255u; j[1] = (uint32_t)(jj + 1) & 255u;
+        k[0] = (uint32_t)kk & 255u; k[1] = (uint32_t)(kk + 1) & 255u;
+    } else {
+        lattice_bytes(fx, i);
+        lattice_bytes(fy, j);
+        lattice_bytes(fz, k);
+    }
     // the tables are expanded at scene creation (DPerlin), which takes the `% point_count` out of every lookup
     uint32_t ix[2] = {pn.permuted(i[0]), pn.permuted(i[1])};
     uint32_t iy[2] = {pn.permuted(256 + j[0]), pn.permuted(256 + j[1])};
