@@ -15,7 +15,7 @@ After the timed region rank 0 repeats one step three times, untimed: with HIP
 events around every launch (per-kernel times: the roofline position of the
 dominant kernel, extend), with the counting build of the kernels (work per
 segment), and with a single pipeline (extend alone on the chip).  On a
-single-GPU run it then measures the other configurations of BASELINE.json and
+single-GPU run it then measures the benchmark's other configurations and
 the CPU baseline (the C++ restatement of the reference with the reference's
 random numbers, on this machine's host cores) and prints ONE JSON line.
 """
@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, MAX_DEPTH, SCENE_ID = 3840, 2160, 25, 8
-JOB_SPP = 4096                       # the configuration BASELINE.json quotes the metric on
+JOB_SPP = 4096                       # the configuration the metric is quoted on
 HBM_PEAK_GBS = 8000.0                # MI355X HBM3E
 FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X FP32 vector
 # Algorithmic bytes per unit of work (one path segment = one ray cast + its shading), the counting this
@@ -49,7 +49,7 @@ NODE_BYTES, SPHERE_BYTES = 128, 16
 # a node visit slab-tests the four child boxes of a node: 4 x 25 flops
 FLOPS = {"node_visits": 100, "sphere_tests": 30, "quad_tests": 45, "hits": 20}
 
-# The other configurations of BASELINE.json on one GPU: (scene id, width, height, depth, samples per call, extra)
+# The benchmark's other configurations on one GPU: (scene id, width, height, depth, samples per call, extra)
 CONFIGS = {
     "C1 Book-1 random spheres 400x225, depth 50, 100 spp per call": (0, 400, 225, 50, 100, {}),
     "C2 earth + perlin spheres 1920x1080, depth 25, 50 spp per call": (100, 1920, 1080, 25, 50, {}),
@@ -68,7 +68,7 @@ def parse_args():
     p.add_argument("--height", type=int, default=HEIGHT)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-configs", action="store_true", help="skip the other configurations of BASELINE.json")
+    p.add_argument("--no-configs", action="store_true", help="skip the benchmark's other configurations")
     p.add_argument("--cpu-spp", type=int, default=384, help="samples per pixel of the 480x270 CPU baseline render")
     return p.parse_args()
 
@@ -121,7 +121,7 @@ def cpu_baseline(spp):
 
 
 def other_configs(rt, device, traffic):
-    """Throughput of BASELINE.json's other configurations: wall clock of whole render calls on one GPU."""
+    """Throughput of the benchmark's other configurations: wall clock of whole render calls on one GPU."""
     out = {}
     for name, (sid, w, h, depth, spp, extra) in CONFIGS.items():
         t0 = time.perf_counter()

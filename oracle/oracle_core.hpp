@@ -70,9 +70,9 @@ struct Seed {
 };
 
 // ---------------------------------------------------------------------------
-// Counter-based generator of the GPU backend (no counterpart in the reference,
-// which BASELINE's north star asks to replace: "rng.rs is replaced by a
-// counter-based per-(pixel, sample, bounce) RNG").  State is a pure function of
+// Counter-based generator of the GPU backend (no counterpart in the reference:
+// it takes the place of src/rng.rs's serial stream per image row, whose draws
+// depend on the order in which rays are processed).  State is a pure function of
 // the key; draws within one (bounce, stream) are sequential xoroshiro64**.
 // ---------------------------------------------------------------------------
 struct CounterStream {
