@@ -39,6 +39,20 @@ static constexpr int STACK_SIZE = (int)TRAVERSAL_STACK_ENTRIES;  // rt_scene_cre
 // leaf tests
 // ---------------------------------------------------------------------------
 
+// Both roots of Sphere::hit / MovingSphere::hit (src/hittable.rs:262-279), oc = origin - centre;
+// false when the discriminant is negative.
+RT_D bool sphere_roots(float3 centre, float radius, float3 o, float3 d, float a, float& near_root, float& far_root) {
+    float3 oc = o - centre;
+    float half_b = dot3(oc, d);
+    float c = dot3(oc, oc) - radius * radius;
+    float disc = half_b * half_b - a * c;
+    if (disc < 0.0f) return false;
+    float sq = sqrtf(disc);
+    near_root = (-half_b - sq) / a;
+    far_root = (-half_b + sq) / a;
+    return true;
+}
+
 // Sphere::hit / MovingSphere::hit root selection (src/hittable.rs:262-279):
 // oc = origin - centre, open interval tmin < root < tmax.
 RT_D bool sphere_root(float3 centre, float radius, float3 o, float3 d, float a, float tmin, float tmax, float& t) {
@@ -174,42 +188,28 @@ struct BatchMediumKey {
     }
 };
 
+// The boundary crossings of a medium whose boundary is one sphere, from the sphere's two roots: each is
+// chosen exactly as Sphere::hit chooses it for the intervals (-inf, inf) and (0.0001 + t1, inf)
+// (ConstantMediumPhase1, src/math/ray.rs:108-128).
+RT_D bool medium_span_of_roots(float near_root, float far_root, float& t1, float& t2) {
+    t1 = near_root;
+    if (!(-RT_INF < t1 && t1 < RT_INF)) {
+        t1 = far_root;
+        if (!(-RT_INF < t1 && t1 < RT_INF)) return false;
+    }
+    float lo = 0.0001f + t1;
+    t2 = near_root;
+    if (!(lo < t2 && t2 < RT_INF)) {
+        t2 = far_root;
+        if (!(lo < t2 && t2 < RT_INF)) return false;
+    }
+    return true;
+}
+
 // ConstantMediumPhase2 (src/math/ray.rs:131-163): free-path sampling inside
 // [t1, t2] clamped to the current interval.
-template <bool COUNT, class Key>
-RT_D bool medium_root(const DScene& sc, uint32_t idx, float3 o, float3 d, float time, float a, float tmin, float tmax,
-                      const Key& key, float& t, Probe& pr) {
-    if (COUNT) pr.media++;
-    DMedium m = sc.media[idx];
-    float t1, t2;
-    if (m.single_sphere) {
-        // Boundary = one sphere in world space: the two queries share oc, half_b, c and the
-        // square root; each root is then chosen exactly as Sphere::hit chooses it for the
-        // intervals (-inf, inf) and (0.0001 + t1, inf).
-        if (COUNT) pr.spheres += 2;
-        float4 sp = m.sphere;
-        float3 oc = o - f3(sp);
-        float half_b = dot3(oc, d);
-        float c = dot3(oc, oc) - sp.w * sp.w;
-        float disc = half_b * half_b - a * c;
-        if (disc < 0.0f) return false;
-        float sq = sqrtf(disc);
-        float near_root = (-half_b - sq) / a, far_root = (-half_b + sq) / a;
-        t1 = near_root;
-        if (!(-RT_INF < t1 && t1 < RT_INF)) {
-            t1 = far_root;
-            if (!(-RT_INF < t1 && t1 < RT_INF)) return false;
-        }
-        float lo = 0.0001f + t1;
-        t2 = near_root;
-        if (!(lo < t2 && t2 < RT_INF)) {
-            t2 = far_root;
-            if (!(lo < t2 && t2 < RT_INF)) return false;
-        }
-    } else {
-        if (!boundary_root<COUNT>(sc, m, o, d, time, a, -RT_INF, RT_INF, t1, pr)) return false;
-        if (!boundary_root<COUNT>(sc, m, o, d, time, a, 0.0001f + t1, RT_INF, t2, pr)) return false;
-    }
+template <class Key>
+RT_D bool medium_sample(const DMedium& m, uint32_t idx, float t1, float t2, float a, float tmin, float tmax, const Key& key, float& t) {
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (t1 >= t2) return false;
@@ -223,6 +223,25 @@ RT_D bool medium_root(const DScene& sc, uint32_t idx, float3 o, float3 d, float 
     if (hit_distance > distance_inside) return false;
     t = t1 + hit_distance / ray_len;
     return true;
+}
+
+template <bool COUNT, class Key>
+RT_D bool medium_root(const DScene& sc, uint32_t idx, float3 o, float3 d, float time, float a, float tmin, float tmax,
+                      const Key& key, float& t, Probe& pr) {
+    if (COUNT) pr.media++;
+    DMedium m = sc.media[idx];
+    float t1, t2;
+    if (m.single_sphere) {
+        // Boundary = one sphere in world space: the two queries share oc, half_b, c and the square root.
+        if (COUNT) pr.spheres += 2;
+        float near_root, far_root;
+        if (!sphere_roots(f3(m.sphere), m.sphere.w, o, d, a, near_root, far_root)) return false;
+        if (!medium_span_of_roots(near_root, far_root, t1, t2)) return false;
+    } else {
+        if (!boundary_root<COUNT>(sc, m, o, d, time, a, -RT_INF, RT_INF, t1, pr)) return false;
+        if (!boundary_root<COUNT>(sc, m, o, d, time, a, 0.0001f + t1, RT_INF, t2, pr)) return false;
+    }
+    return medium_sample(m, idx, t1, t2, a, tmin, tmax, key, t);
 }
 
 // ---------------------------------------------------------------------------
@@ -424,9 +443,32 @@ RT_D uint32_t leaf_step(const DScene& sc, const TravRay& r, uint32_t cur, float&
     return pop_next(st, tmax);
 }
 
+// The reference's box test of a sphere leaf in world space (AABB::from_points(c - r, c + r), src/hittable.rs:160-163,
+// tested as src/math/aabb.rs:127-167 tests it).  When the origin lies inside the box, at least 2 tmin |d_k| from
+// every face, the test passes whatever the rounding: each entry distance is negative, each exit distance is
+// at least 2 tmin (1 - 2^-22) > tmin, so the interval is [tmin, min(exits, tmax)] and not empty.  That case needs no
+// division; every other ray takes the test itself.
+RT_D bool sphere_box_test(float4 s, const TravRay& r, float tmax) {
+    const float3 lo = f3(s.x - s.w, s.y - s.w, s.z - s.w), hi = f3(s.x + s.w, s.y + s.w, s.z + s.w);
+    const float m = fminf(fminf(fminf(r.o.x - lo.x, hi.x - r.o.x), fminf(r.o.y - lo.y, hi.y - r.o.y)), fminf(r.o.z - lo.z, hi.z - r.o.z));
+    const float two_tmin = 2.0f * r.tmin;
+    if (m > 0.0f && m >= two_tmin * fabsf(r.d.x) && m >= two_tmin * fabsf(r.d.y) && m >= two_tmin * fabsf(r.d.z) && r.tmin <= tmax)
+        return true;
+    const float3 inv = f3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    float x0 = (lo.x - r.o.x) * inv.x, x1 = (hi.x - r.o.x) * inv.x;
+    float y0 = (lo.y - r.o.y) * inv.y, y1 = (hi.y - r.o.y) * inv.y;
+    float z0 = (lo.z - r.o.z) * inv.z, z1 = (hi.z - r.o.z) * inv.z;
+    float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), r.tmin));
+    float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+    return t_in <= t_out;
+}
+
 // Leaves whose boxes span (almost) the whole scene are kept out of the tree and tested first,
 // by every lane at once.  A sphere still passes through the reference's box test of that leaf
-// (AABB::from_points(c - r, c + r), src/hittable.rs:160-163) before Sphere::hit is evaluated.
+// before Sphere::hit is evaluated.  A sphere followed by a medium bounded by that same sphere (a
+// glass ball filled with fog, or the mist that fills a whole scene inside its boundary sphere) is
+// one quadratic: both leaves take their roots from it, in the order and with the intervals they
+// would have had one after the other.
 template <bool COUNT, class Key>
 RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_t& best, const Key& key, Probe& pr) {
     for (uint32_t g = 0; g < sc.n_global; ++g) {
@@ -436,13 +478,36 @@ RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_
         if (ref_kind(ref) == KIND_MEDIUM) {
             hit = medium_root<COUNT>(sc, ref_index(ref), r.o, r.d, r.time, r.a, r.tmin, tmax, key, t, pr);
         } else {
-            float4 s = sc.spheres[ref_index(ref)];
-            float x0 = ((s.x - s.w) - r.o.x) * r.inv.x, x1 = ((s.x + s.w) - r.o.x) * r.inv.x;
-            float y0 = ((s.y - s.w) - r.o.y) * r.inv.y, y1 = ((s.y + s.w) - r.o.y) * r.inv.y;
-            float z0 = ((s.z - s.w) - r.o.z) * r.inv.z, z1 = ((s.z + s.w) - r.o.z) * r.inv.z;
-            float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), r.tmin));
-            float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
-            hit = t_in <= t_out && leaf_root<COUNT>(sc, ref, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr);
+            const float4 s = sc.spheres[ref_index(ref)];
+            const uint32_t next = g + 1 < sc.n_global ? sc.global_refs[g + 1] : REF_NONE;
+            if (next != REF_NONE && ref_kind(next) == KIND_MEDIUM) {
+                const DMedium m = sc.media[ref_index(next)];
+                if (m.single_sphere && m.sphere.x == s.x && m.sphere.y == s.y && m.sphere.z == s.z && m.sphere.w == s.w) {
+                    if (COUNT) { pr.spheres += 3; pr.media++; }
+                    float near_root, far_root;
+                    if (sphere_roots(f3(s), s.w, r.o, r.d, r.a, near_root, far_root)) {
+                        float root = near_root;
+                        bool in = r.tmin < root && root < tmax;
+                        if (!in) {
+                            root = far_root;
+                            in = r.tmin < root && root < tmax;
+                        }
+                        if (in && sphere_box_test(s, r, tmax)) {
+                            tmax = root;
+                            best = ref;
+                        }
+                        float t1, t2;
+                        if (medium_span_of_roots(near_root, far_root, t1, t2) &&
+                            medium_sample(m, ref_index(next), t1, t2, r.a, r.tmin, tmax, key, t)) {
+                            tmax = t;
+                            best = next;
+                        }
+                    }
+                    ++g;
+                    continue;
+                }
+            }
+            hit = sphere_box_test(s, r, tmax) && leaf_root<COUNT>(sc, ref, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr);
         }
         if (hit) {
             tmax = t;
