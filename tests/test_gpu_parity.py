@@ -1078,6 +1078,60 @@ def test_random_rays_from_inside_the_scenes(sid, extent):
     assert 0.3 < want["hit"].mean()
 
 
+def _big_sphere_scene(s):
+    """Leaves that are tested ahead of the tree: a glass sphere of radius 50 with the mist it bounds, a second big sphere
+    without a medium, a big medium bounded by a sphere that is not a leaf itself, and a few small things in a tree."""
+    t = s.tex_solid(0.6, 0.6, 0.7)
+    lam, glass = s.lambertian(t), s.dielectric(t, 1.5)
+    items = [s.sphere((0, 0, 0), 50.0, glass), s.medium(s.sphere((0, 0, 0), 50.0, glass), 0.02, t),
+             s.sphere((10, 0, 0), 45.0, glass),
+             s.medium(s.sphere((-5, 3, 0), 48.0, lam), 0.01, t)]
+    for i in range(6):
+        items.append(s.sphere((6.0 * i - 15, 0.5 * i, 3.0), 1.0 + 0.2 * i, lam))
+    s.set_world(s.bvh(items))
+    s.camera((0, 0, -20), 32, 32, max_depth=4, vfov=60.0, background=(0.7, 0.8, 0.9), yaw=90.0)
+    return s
+
+
+def test_origins_near_the_faces_of_the_boxes_of_leaves_tested_ahead_of_the_tree():
+    """A sphere leaf is box-tested before Sphere::hit (src/hittable.rs:160-163, src/math/aabb.rs:127-167); for the leaves
+    tested ahead of the tree the kernels skip the divisions of that test when the origin is well inside the box, and take
+    the roots of a sphere and of the medium it bounds from one quadratic.  Origins within a few ulp, 1e-4 ... 1 of the box
+    faces (inside and outside), directions of lengths 1e-3 ... 1e4 so that the margin rule switches between its two sides:
+    every decision must be the restatement's, t bit-equal on the spheres."""
+    gpu, cpu = _big_sphere_scene(rt.Scene()), _big_sphere_scene(ob.OracleScene())
+    assert gpu.info()["leaves_tested_first"] == 4
+    rng = np.random.default_rng(99)
+    n = 40000
+    faces = np.array([-50.0, 50.0, -35.0, 55.0, -53.0, 43.0, -45.0, 51.0, -48.0, 48.0], np.float32)
+    origin = rng.uniform(-40, 40, (n, 3)).astype(np.float32)
+    near = rng.random((n, 3)) < 0.3
+    delta = rng.choice(np.array([0.0, 1e-5, 1e-4, 1e-3, 1e-2, 0.1, 1.0], np.float32), (n, 3)) * rng.choice(np.array([-1, 1], np.float32), (n, 3))
+    on_face = rng.choice(faces, (n, 3)) + delta
+    steps = rng.integers(-2, 3, (n, 3))
+    on_face = np.where(steps > 0, np.nextafter(on_face, np.float32(np.inf)), np.where(steps < 0, np.nextafter(on_face, np.float32(-np.inf)), on_face))
+    origin = np.where(near, on_face, origin).astype(np.float32)
+    rays = np.zeros(n, _abi.ray_dtype())
+    rays["origin"] = origin
+    rays["direction"] = (rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-3, 4, (n, 1))).astype(np.float32)
+    axis = rng.random(n) < 0.2                              # some exactly along an axis (1 / 0 in the box test)
+    rays["direction"][axis] *= np.eye(3, dtype=np.float32)[rng.integers(0, 3, axis.sum())]
+    rays["time"] = rng.uniform(0, 1, n)
+    rays["tmin"], rays["tmax"] = 0.001, np.inf
+    rays["rng_pixel"], rays["rng_sample"], rays["rng_bounce"] = np.arange(n) % 4096, 1 + np.arange(n) // 4096, rng.integers(0, 4, n)
+    in_plane = ((rays["direction"] == 0) & np.isin(origin, faces)).any(axis=1)   # 0 * inf = NaN in a box test: see the test of axis-parallel rays
+    want = cpu.intersect(rays, seed=11)
+    a, b = gpu.intersect(rays, seed=11), gpu.extend(rays, seed=11)
+    _same_records(a, b)
+    keep = ~in_plane
+    assert np.array_equal(a["hit"][keep], want["hit"][keep]) and 0.15 < want["hit"].mean() < 1.0
+    hit = keep & (want["hit"] == 1)
+    assert np.array_equal(a["prim_id"][hit], want["prim_id"][hit])
+    on_sphere = hit & ~np.isin(want["prim_id"], (2, 5))     # primitives are numbered as they are made: 2 and 5 are the media
+    assert on_sphere.sum() > 1000 and np.array_equal(a["t"][on_sphere], want["t"][on_sphere])
+    assert (np.abs(a["t"][hit] - want["t"][hit]) <= 1e-5 * np.maximum(1.0, np.abs(want["t"][hit]))).all()
+
+
 def test_extend_kernel_rejects_rays_the_render_path_never_casts():
     s = rt.Scene.builtin(6, 16, 16)
     rays = s.primary_rays(np.arange(4, dtype=np.uint32), 1)
