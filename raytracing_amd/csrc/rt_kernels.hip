@@ -446,13 +446,13 @@ RT_D uint32_t leaf_step(const DScene& sc, const TravRay& r, uint32_t cur, float&
 // The reference's box test of a sphere leaf in world space (AABB::from_points(c - r, c + r), src/hittable.rs:160-163,
 // tested as src/math/aabb.rs:127-167 tests it).  When the origin lies inside the box, at least 2 tmin |d_k| from
 // every face, the test passes whatever the rounding: each entry distance is negative, each exit distance is
-// at least 2 tmin (1 - 2^-22) > tmin, so the interval is [tmin, min(exits, tmax)] and not empty.  That case needs no
-// division; every other ray takes the test itself.
+// at least 2 tmin (1 - 2^-22) >= tmin (tmin >= 0), so the interval is [tmin, min(exits, tmax)] and not empty.  That case
+// needs no division; every other ray takes the test itself.
 RT_D bool sphere_box_test(float4 s, const TravRay& r, float tmax) {
     const float3 lo = f3(s.x - s.w, s.y - s.w, s.z - s.w), hi = f3(s.x + s.w, s.y + s.w, s.z + s.w);
     const float m = fminf(fminf(fminf(r.o.x - lo.x, hi.x - r.o.x), fminf(r.o.y - lo.y, hi.y - r.o.y)), fminf(r.o.z - lo.z, hi.z - r.o.z));
     const float two_tmin = 2.0f * r.tmin;
-    if (m > 0.0f && m >= two_tmin * fabsf(r.d.x) && m >= two_tmin * fabsf(r.d.y) && m >= two_tmin * fabsf(r.d.z) && r.tmin <= tmax)
+    if (m > 0.0f && m >= two_tmin * fabsf(r.d.x) && m >= two_tmin * fabsf(r.d.y) && m >= two_tmin * fabsf(r.d.z) && 0.0f <= r.tmin && r.tmin <= tmax)
         return true;
     const float3 inv = f3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     float x0 = (lo.x - r.o.x) * inv.x, x1 = (hi.x - r.o.x) * inv.x;

@@ -1130,6 +1130,15 @@ def test_origins_near_the_faces_of_the_boxes_of_leaves_tested_ahead_of_the_tree(
     on_sphere = hit & ~np.isin(want["prim_id"], (2, 5))     # primitives are numbered as they are made: 2 and 5 are the media
     assert on_sphere.sum() > 1000 and np.array_equal(a["t"][on_sphere], want["t"][on_sphere])
     assert (np.abs(a["t"][hit] - want["t"][hit]) <= 1e-5 * np.maximum(1.0, np.abs(want["t"][hit]))).all()
+    # intervals no render casts (the per-ray entry point takes them): zero, negative and empty ones
+    odd = rays[keep][:12000].copy()
+    odd["tmin"] = rng.choice(np.array([0.0, -2.0, 0.5, 0.001, 30.0], np.float32), len(odd))
+    odd["tmax"] = rng.choice(np.array([-1.0, 0.0005, 10.0, 80.0, np.inf], np.float32), len(odd))
+    want, got = cpu.intersect(odd, seed=11), gpu.intersect(odd, seed=11)
+    assert np.array_equal(got["hit"], want["hit"]) and 0.05 < want["hit"].mean()
+    hit = want["hit"] == 1
+    assert np.array_equal(got["prim_id"][hit], want["prim_id"][hit])
+    assert (np.abs(got["t"][hit] - want["t"][hit]) <= 1e-5 * np.maximum(1.0, np.abs(want["t"][hit]))).all()
 
 
 def test_extend_kernel_rejects_rays_the_render_path_never_casts():
