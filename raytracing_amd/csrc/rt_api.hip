@@ -842,6 +842,35 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         }
     };
     for (uint32_t i = 0; i < desc->n_boundary; ++i) boundary_refs[i] = make_leaf(desc->boundary[i].kind, desc->boundary[i].index, placed(desc->boundary[i]));
+    // The reference's own box of every boundary leaf, in the leaf's space (a placed leaf sits in object space under its
+    // Move / RotateY there too): Hittable::calc_aabb for a sphere, a moving sphere and a quad (src/hittable.rs:160-175).
+    // A boundary of several leaves is a BVH in the reference, whose nodes test these boxes before the leaves.
+    std::vector<float4> boundary_boxes(2 * (size_t)desc->n_boundary);
+    for (uint32_t i = 0; i < desc->n_boundary; ++i) {
+        const rt_prim_ref& r = desc->boundary[i];
+        Aabb own;
+        if (r.kind == RT_PRIM_SPHERE) {
+            const rt_sphere& sp = desc->spheres[r.index];
+            float lo[3] = {sp.centre[0] - sp.radius, sp.centre[1] - sp.radius, sp.centre[2] - sp.radius};
+            float hi[3] = {sp.centre[0] + sp.radius, sp.centre[1] + sp.radius, sp.centre[2] + sp.radius};
+            own = Aabb::from_points(lo, hi);
+        } else if (r.kind == RT_PRIM_MOVING_SPHERE) {
+            const rt_moving_sphere& sp = desc->moving_spheres[r.index];
+            float rad = sp.radius, lo[3], hi[3], lo1[3], hi1[3];
+            for (int a = 0; a < 3; ++a) {
+                float at0 = sp.centre0[a] + 0.0f * sp.dcentre[a], at1 = sp.centre0[a] + 1.0f * sp.dcentre[a];
+                lo[a] = at0 - rad; hi[a] = at0 + rad; lo1[a] = at1 - rad; hi1[a] = at1 + rad;
+            }
+            own = Aabb::from_aabbs(Aabb::from_points(lo, hi), Aabb::from_points(lo1, hi1));
+        } else {
+            const rt_quad& qd = desc->quads[r.index];
+            float quv[3], qu[3], qv[3];
+            for (int a = 0; a < 3; ++a) { qu[a] = qd.q[a] + qd.u[a]; qv[a] = qd.q[a] + qd.v[a]; quv[a] = qu[a] + qd.v[a]; }
+            own = Aabb::from_aabbs(Aabb::from_points(qd.q, quv), Aabb::from_points(qu, qv));
+        }
+        boundary_boxes[2 * (size_t)i] = make_float4(own.mn[0], own.mn[1], own.mn[2], 0.0f);
+        boundary_boxes[2 * (size_t)i + 1] = make_float4(own.mx[0], own.mx[1], own.mx[2], 0.0f);
+    }
     bool media_are_single_spheres = true;
     for (uint32_t i = 0; i < desc->n_media; ++i) {
         const rt_medium& m = desc->media[i];
@@ -933,6 +962,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     sc->bvh_depth = bvh.max_depth;
     sc->stack_need = bvh.stack_need;
     sc->media_are_single_spheres = media_are_single_spheres;
+    sc->d.generic_media = media_are_single_spheres ? 0u : 1u;
     auto bail = [&](int code) { rt_scene_destroy(sc); return code; };
 
     std::vector<float4> nodes(bvh.nodes.size() / 4);
@@ -947,6 +977,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     if ((e = upload(sc, media, &sc->d.media))) return bail(e);
     if ((e = upload(sc, medium_meta, &sc->d.medium_meta))) return bail(e);
     if ((e = upload(sc, boundary_refs, &sc->d.boundary_refs))) return bail(e);
+    if ((e = upload(sc, boundary_boxes, &sc->d.boundary_boxes))) return bail(e);
     if ((e = upload(sc, xforms, &sc->d.xforms))) return bail(e);
     {   // per-leaf copies of the placements, for the kinds that have placed leaves
         auto per_leaf = [&](size_t n, auto transform_of, const float4** out) -> int {

@@ -124,6 +124,7 @@ struct DScene {
     const DMedium* media;
     const uint4* medium_meta;
     const uint32_t* boundary_refs;
+    const float4* boundary_boxes;  // 2 x float4 per boundary reference: min, max of the leaf's own box in the leaf's space
     const float4* xforms;      // 2 x float4 per placement
     // the placement of leaf i once more at [2 i], [2 i + 1] (NULL when no leaf of the kind is placed):
     // a leaf test reads it together with the primitive instead of after it
@@ -141,6 +142,7 @@ struct DScene {
     uint32_t n_materials;
     uint32_t n_global;         // leaves kept out of the tree: tested first for every ray
     uint32_t lds_perlin;       // 1: the scene has exactly one noise table and it fits the textured-shade kernel's LDS copy
+    uint32_t generic_media;    // 1: some medium's boundary is not one sphere in world space (selects the kernels that hold the code for those)
     const uint32_t* global_refs;  // n_global leaf references tested ahead of the tree
 };
 

@@ -153,16 +153,51 @@ RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float ti
     }
 }
 
+// AABB::hit / AABBx2::hit (src/math/aabb.rs:32-49,127-167) for one box and the interval [lo, hi]: min / max that drop a
+// NaN, the interval as the fourth lane of the reductions.
+RT_D bool own_box_test(float4 mn, float4 mx, float3 o, float3 d, float lo, float hi) {
+    const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float x0 = (mn.x - o.x) * inv.x, x1 = (mx.x - o.x) * inv.x;
+    const float y0 = (mn.y - o.y) * inv.y, y1 = (mx.y - o.y) * inv.y;
+    const float z0 = (mn.z - o.z) * inv.z, z1 = (mx.z - o.z) * inv.z;
+    const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), fminf(lo, hi)));
+    const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), fmaxf(lo, hi)));
+    return t_in <= t_out;
+}
+
+// A leaf of a medium's boundary that consists of several leaves: in the reference such a boundary is a BVH (a box is the
+// BVH of its six quads, src/hittable.rs:81-100), whose nodes test each leaf's own box - in the leaf's space, under its
+// Move / RotateY - before the leaf.  For the thin box of a quad the outcome of that test matters: far along a ray, where
+// t + 0.0001 == t, it is what keeps the second boundary query from finding the first one's quad again.
+template <bool COUNT>
+RT_D bool boundary_leaf_root(const DScene& sc, uint32_t ref, const float4* __restrict__ box, float3 o, float3 d, float time, float a,
+                             float lo, float hi, float& t, Probe& pr) {
+    if (ref_placed(ref)) {
+        const uint32_t kind = ref_kind(ref), idx = ref_index(ref);
+        const float4* xf = (kind == KIND_SPHERE ? sc.sphere_xf : kind == KIND_MOVING ? sc.moving_xf : sc.quad_xf) + 2 * (size_t)idx;
+        float3 oo = o, dd = d;
+        ray_to_object(xf[0], xf[1], oo, dd);
+        if (!own_box_test(box[0], box[1], oo, dd, lo, hi)) return false;
+    } else if (!own_box_test(box[0], box[1], o, d, lo, hi)) {
+        return false;
+    }
+    return leaf_root<COUNT>(sc, ref, o, d, time, a, lo, hi, t, pr);
+}
+
 // Closest hit of a medium's boundary object inside (lo, hi): the two nested
 // queries of ConstantMediumPhase1/2 (src/math/ray.rs:108-128,250-265).
 template <bool COUNT>
 RT_D bool boundary_root(const DScene& sc, const DMedium& m, float3 o, float3 d, float time, float a, float lo, float hi, float& t,
                         Probe& pr) {
     bool any = false;
+    if (m.n_boundary == 1) {  // a lone leaf: tested directly
+        any = leaf_root<COUNT>(sc, sc.boundary_refs[m.first_boundary], o, d, time, a, lo, hi, t, pr);
+        return any;
+    }
     for (uint32_t i = 0; i < m.n_boundary; ++i) {
         uint32_t ref = sc.boundary_refs[m.first_boundary + i];
         float tt;
-        if (leaf_root<COUNT>(sc, ref, o, d, time, a, lo, hi, tt, pr)) {
+        if (boundary_leaf_root<COUNT>(sc, ref, sc.boundary_boxes + 2 * (size_t)(m.first_boundary + i), o, d, time, a, lo, hi, tt, pr)) {
             any = true;
             hi = tt;
         }
@@ -225,13 +260,15 @@ RT_D bool medium_sample(const DMedium& m, uint32_t idx, float t1, float t2, floa
     return true;
 }
 
-template <bool COUNT, class Key>
+// GENERIC false: the scene's media are all bounded by one sphere in world space each (DScene::generic_media is 0), and the
+// code for every other boundary stays out of the kernel - it costs the traversal kernel registers it does not have.
+template <bool COUNT, bool GENERIC, class Key>
 RT_D bool medium_root(const DScene& sc, uint32_t idx, float3 o, float3 d, float time, float a, float tmin, float tmax,
                       const Key& key, float& t, Probe& pr) {
     if (COUNT) pr.media++;
     DMedium m = sc.media[idx];
     float t1, t2;
-    if (m.single_sphere) {
+    if (!GENERIC || m.single_sphere) {
         // Boundary = one sphere in world space: the two queries share oc, half_b, c and the square root.
         if (COUNT) pr.spheres += 2;
         float near_root, far_root;
@@ -429,12 +466,12 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
 #endif
 
 // One leaf: primitive or medium test; a hit shrinks tmax.  Returns the next reference.
-template <bool COUNT, class Stack, class Key>
+template <bool COUNT, bool GENERIC, class Stack, class Key>
 RT_D uint32_t leaf_step(const DScene& sc, const TravRay& r, uint32_t cur, float& tmax, uint32_t& best, const Key& key, Stack& st,
                         Probe& pr) {
     float t;
     bool hit;
-    if (ref_kind(cur) == KIND_MEDIUM) hit = medium_root<COUNT>(sc, ref_index(cur), r.o, r.d, r.time, r.a, r.tmin, tmax, key, t, pr);
+    if (ref_kind(cur) == KIND_MEDIUM) hit = medium_root<COUNT, GENERIC>(sc, ref_index(cur), r.o, r.d, r.time, r.a, r.tmin, tmax, key, t, pr);
     else hit = leaf_root<COUNT>(sc, cur, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr);
     if (hit) {
         tmax = t;
@@ -469,14 +506,14 @@ RT_D bool sphere_box_test(float4 s, const TravRay& r, float tmax) {
 // glass ball filled with fog, or the mist that fills a whole scene inside its boundary sphere) is
 // one quadratic: both leaves take their roots from it, in the order and with the intervals they
 // would have had one after the other.
-template <bool COUNT, class Key>
+template <bool COUNT, bool GENERIC, class Key>
 RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_t& best, const Key& key, Probe& pr) {
     for (uint32_t g = 0; g < sc.n_global; ++g) {
         uint32_t ref = sc.global_refs[g];
         float t;
         bool hit;
         if (ref_kind(ref) == KIND_MEDIUM) {
-            hit = medium_root<COUNT>(sc, ref_index(ref), r.o, r.d, r.time, r.a, r.tmin, tmax, key, t, pr);
+            hit = medium_root<COUNT, GENERIC>(sc, ref_index(ref), r.o, r.d, r.time, r.a, r.tmin, tmax, key, t, pr);
         } else {
             const float4 s = sc.spheres[ref_index(ref)];
             const uint32_t next = g + 1 < sc.n_global ? sc.global_refs[g + 1] : REF_NONE;
@@ -520,13 +557,14 @@ RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_
 // hit among those leaves, as the hit record the extend kernel then improves on.  Ray generation
 // computes it with the ray still in registers; for the rays shade creates, a streaming pass of
 // its own (k_first_leaves) is faster than doing it inside the shade kernel's tile loop.
+template <bool GENERIC>
 RT_D uint2 first_leaves_hit(const DScene& sc, const BatchInfo& b, uint64_t seed, uint32_t bounce, float4 ro, float4 rd) {
     BatchMediumKey key{seed, __float_as_uint(rd.w), bounce, b};
     TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
     float tmax = RT_INF;
     uint32_t best = REF_NONE;
     Probe pr;
-    global_leaves<false>(sc, r, tmax, best, key, pr);
+    global_leaves<false, GENERIC>(sc, r, tmax, best, key, pr);
     return make_uint2(__float_as_uint(tmax), best);
 }
 
@@ -541,7 +579,7 @@ RT_D void walk_tree(const DScene& sc, const TravRay& r, float& tmax, uint32_t& b
     uint32_t cur = sc.root == REF_NONE ? REF_DONE : sc.root;
     while (cur != REF_DONE) {
         if (!ref_is_leaf(cur)) cur = node_step<COUNT, false>(src, r, cur, tmax, st, pr);
-        else cur = leaf_step<COUNT>(sc, r, cur, tmax, best, key, st, pr);
+        else cur = leaf_step<COUNT, true>(sc, r, cur, tmax, best, key, st, pr);
     }
 }
 
@@ -550,7 +588,7 @@ RT_D uint32_t closest_hit(const DScene& sc, float3 o, float3 d, float time, floa
                           Probe& pr) {
     uint32_t best = REF_NONE;
     TravRay r = make_trav_ray(o, d, time, tmin);
-    global_leaves<COUNT>(sc, r, tmax, best, key, pr);
+    global_leaves<COUNT, true>(sc, r, tmax, best, key, pr);
     PrivateStack st;
     walk_tree<COUNT>(sc, r, tmax, best, key, st, pr);
     t_hit = tmax;
@@ -987,6 +1025,7 @@ RT_D void primary_ray(const DCamera& cam, uint64_t seed, uint32_t pixel, uint32_
 
 // One thread per path of the batch.  s_local * n_pixels + pixel_local is the path's initial queue slot and its
 // slot in the radiance array.
+template <bool GENERIC>
 __global__ __launch_bounds__(256) void k_raygen(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, float4* __restrict__ ray_o,
                                                 float4* __restrict__ ray_d, float* __restrict__ thr, uint2* __restrict__ first_hits,
                                                 uint32_t* __restrict__ counts, uint32_t n_counts) {
@@ -1005,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_raygen(DScene sc, DCamera cam, BatchInf
         ray_o[i] = ro;
         ray_d[i] = rd;
         store_thr(thr, i, make_float4(1.0f, 1.0f, 1.0f, 0.0f));
-        if (first_hits) first_hits[i] = first_leaves_hit(sc, b, seed, 0, ro, rd);
+        if (first_hits) first_hits[i] = first_leaves_hit<GENERIC>(sc, b, seed, 0, ro, rd);
     }
 }
 
@@ -1054,7 +1093,7 @@ static constexpr int OVERFLOW_STACK = STACK_SIZE - MIN_LDS_STACK;
 #ifndef RT_EXTEND_WAVES
 #define RT_EXTEND_WAVES 6  // resident waves per SIMD the register allocation aims for
 #endif
-template <bool COUNT, bool SMALL_TREE>
+template <bool COUNT, bool SMALL_TREE, bool GENERIC>
 __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_EXTEND_WAVES, RT_EXTEND_WAVES))) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                          const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
                                                          const float4* __restrict__ ray_d, uint2* __restrict__ hits,
@@ -1198,7 +1237,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(RT
 #endif
                     if (at_medium) {
                         float t;
-                        if (medium_root<COUNT>(sc, ref_index(cur), r.o, r.d, r.time, r.a, r.tmin, tmax, key, t, pr)) { tmax = t; best = cur; }
+                        if (medium_root<COUNT, GENERIC>(sc, ref_index(cur), r.o, r.d, r.time, r.a, r.tmin, tmax, key, t, pr)) { tmax = t; best = cur; }
                         cur = pop_next(st, tmax);
                     }
                 }
@@ -1211,7 +1250,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(RT
 
 // Runs ahead of k_extend when the scene has leaves that are kept out of the tree: tests them
 // for every ray of the queue with all lanes busy, and leaves the closest hit so far in hits[].
-template <bool COUNT>
+template <bool COUNT, bool GENERIC>
 __global__ __launch_bounds__(256) void k_first_leaves(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                       const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
                                                       const float4* __restrict__ ray_d, uint2* __restrict__ hits, DCounters* counters) {
@@ -1223,7 +1262,7 @@ __global__ __launch_bounds__(256) void k_first_leaves(DScene sc, BatchInfo b, ui
         TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
         float tmax = RT_INF;
         uint32_t best = REF_NONE;
-        global_leaves<COUNT>(sc, r, tmax, best, key, pr);
+        global_leaves<COUNT, GENERIC>(sc, r, tmax, best, key, pr);
         hits[i] = make_uint2(__float_as_uint(tmax), best);
     }
     if (COUNT) flush_probe(counters, pr, 0, 0);
@@ -1521,7 +1560,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(DScene sc, DCamera cam, Bat
             const TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
             float tmax = RT_INF;
             uint32_t best = REF_NONE;
-            global_leaves<false>(sc, r, tmax, best, key, pr);
+            global_leaves<false, true>(sc, r, tmax, best, key, pr);
             st.sp = 0;
             walk_tree<false>(sc, r, tmax, best, key, st, pr);
             float4 no, nd, nt;
@@ -1702,7 +1741,7 @@ static inline uint32_t grid_for(unsigned long long n, uint32_t max_blocks) {
 void launch_raygen(hipStream_t st, uint32_t max_blocks, const DScene& sc, const DCamera& cam, const BatchInfo& b, uint64_t seed, float4* ray_o,
                    float4* ray_d, float* thr, uint2* first_hits, uint32_t* counts, uint32_t n_counts) {
     uint32_t total = b.n_pixels * b.n_samples;
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for(total, max_blocks)), dim3(256), 0, st, sc, cam, b, seed, ray_o, ray_d, thr,
+    hipLaunchKernelGGL(sc.generic_media ? k_raygen<true> : k_raygen<false>, dim3(grid_for(total, max_blocks)), dim3(256), 0, st, sc, cam, b, seed, ray_o, ray_d, thr,
                        sc.n_global != 0 ? first_hits : nullptr, counts, n_counts);
 }
 
@@ -1717,14 +1756,18 @@ void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam
 // share of the queue on an almost empty chip.
 int extend_blocks_per_cu(bool counting) {
     int a = 0;
-    int b = 0;
-    hipError_t e = counting ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_extend<true, false>, EXTEND_BLOCK, 0)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_extend<false, false>, EXTEND_BLOCK, 0);
-    if (e != hipSuccess) a = 0;
-    e = counting ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_extend<true, true>, EXTEND_BLOCK, 0)
-                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_extend<false, true>, EXTEND_BLOCK, 0);
-    if (e != hipSuccess) b = 0;
-    a = std::min(a, b);
+    // the smallest figure over the variants of the kernel (large / small tree, with / without the code for media of any boundary)
+    auto blocks_of = [](auto kernel) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, EXTEND_BLOCK, 0) != hipSuccess) n = 0;
+        return n;
+    };
+    if (counting)
+        a = std::min(std::min(blocks_of(k_extend<true, false, false>), blocks_of(k_extend<true, true, false>)),
+                     std::min(blocks_of(k_extend<true, false, true>), blocks_of(k_extend<true, true, true>)));
+    else
+        a = std::min(std::min(blocks_of(k_extend<false, false, false>), blocks_of(k_extend<false, true, false>)),
+                     std::min(blocks_of(k_extend<false, false, true>), blocks_of(k_extend<false, true, true>)));
     (void)hipGetLastError();
     // a block whose LDS divides the CU's 160 KiB exactly does not get the last slot in practice
     int by_lds = (int)((160u * 1024u - 1024u) / (2048u * (uint32_t)RT_EXTEND_STACK + 16u));  // 2 KiB per stack level and block
@@ -1745,8 +1788,9 @@ size_t extend_overflow_bytes(uint32_t blocks) { return (size_t)blocks * (EXTEND_
 void launch_first_leaves(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
                          uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits, DCounters* counters) {
     dim3 g0(grid_for(upper_bound, max_blocks * 4u));
-    if (counters) hipLaunchKernelGGL(k_first_leaves<true>, g0, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
-    else hipLaunchKernelGGL(k_first_leaves<false>, g0, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
+    auto kernel = counters ? (sc.generic_media ? k_first_leaves<true, true> : k_first_leaves<true, false>)
+                           : (sc.generic_media ? k_first_leaves<false, true> : k_first_leaves<false, false>);
+    hipLaunchKernelGGL(kernel, g0, dim3(256), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, counters);
 }
 
 void launch_extend(hipStream_t st, uint32_t resident_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
@@ -1754,7 +1798,9 @@ void launch_extend(hipStream_t st, uint32_t resident_blocks, uint32_t upper_boun
                    unsigned long long* stack_overflow, const ExtendTuning& tune, DCounters* counters) {
     dim3 grid(grid_for(upper_bound, resident_blocks));
     const bool small_tree = sc.n_nodes <= (uint32_t)SMALL_TREE_NODES;
-    auto kernel = counters ? (small_tree ? k_extend<true, true> : k_extend<true, false>) : (small_tree ? k_extend<false, true> : k_extend<false, false>);
+    auto kernel = sc.generic_media
+        ? (counters ? (small_tree ? k_extend<true, true, true> : k_extend<true, false, true>) : (small_tree ? k_extend<false, true, true> : k_extend<false, false, true>))
+        : (counters ? (small_tree ? k_extend<true, true, false> : k_extend<true, false, false>) : (small_tree ? k_extend<false, true, false> : k_extend<false, false, false>));
     hipLaunchKernelGGL(kernel, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, stack_overflow, tune, counters);
 }
 
