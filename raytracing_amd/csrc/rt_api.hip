@@ -102,6 +102,8 @@ struct rt_ctx {
     uint32_t max_blocks = 2048;
     uint32_t extend_blocks = 1024;  // persistent grid of the extend kernel: what the chip holds at once
     uint32_t extend_blocks_counting = 1024;  // the same for its counting build (more registers)
+    uint32_t extend_blocks_generic = 1024, extend_blocks_counting_generic = 1024;  // the same for the variants that scenes with
+                                                                                  // media of any boundary get (never more blocks)
     uint32_t tail_blocks = 512;     // what the chip holds of the tail kernel
     rt::ExtendTuning tune;
     uint64_t batch_paths = DEFAULT_BATCH_PATHS;
@@ -455,6 +457,11 @@ uint32_t tail_start_for(rt_ctx* c, const rt_scene* sc, const rt_camera_desc* cam
     return bounce;
 }
 
+// persistent grid of the extend kernel variant this scene runs (never more than the overflow area is sized for)
+uint32_t extend_grid_of(const rt_ctx* c, const rt_scene* sc, bool counting) {
+    if (sc->d.generic_media) return counting ? c->extend_blocks_counting_generic : c->extend_blocks_generic;
+    return counting ? c->extend_blocks_counting : c->extend_blocks;
+}
 bool needs_overflow(const rt_scene* sc) { return sc->stack_need > (uint32_t)rt::extend_lds_stack_levels(sc->d.n_nodes); }
 
 DCamera to_dcamera(const rt_camera_desc* c) {
@@ -508,12 +515,18 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     c->device = device_id;
     c->max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
     {
-        int per_cu = rt::extend_blocks_per_cu(false), per_cu_counting = rt::extend_blocks_per_cu(true);
+        int per_cu = rt::extend_blocks_per_cu(false, false), per_cu_counting = rt::extend_blocks_per_cu(true, false);
+        int per_cu_generic = rt::extend_blocks_per_cu(false, true), per_cu_counting_generic = rt::extend_blocks_per_cu(true, true);
         if (const char* e = getenv("RT_AMD_EXTEND_BLOCKS_PER_CU")) per_cu = atoi(e);  // tuning experiments only
         if (per_cu < 1) per_cu = 4;
         if (per_cu_counting < 1) per_cu_counting = 3;
         c->extend_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)per_cu;
         c->extend_blocks_counting = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::min(per_cu, per_cu_counting);
+        if (per_cu_generic < 1) per_cu_generic = 3;
+        if (per_cu_counting_generic < 1) per_cu_counting_generic = 3;
+        c->extend_blocks_generic = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::min(per_cu, per_cu_generic);
+        c->extend_blocks_counting_generic =
+            (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::min(std::min(per_cu, per_cu_generic), per_cu_counting_generic);
         c->tail_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::max(1, rt::tail_blocks_per_cu());
         if (const char* e = getenv("RT_AMD_EXTEND_TUNING"))  // "inner,refill,medium": tuning experiments only
             sscanf(e, "%d,%d,%d", &c->tune.inner_min, &c->tune.refill_min, &c->tune.medium_min);
@@ -876,7 +889,14 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         const rt_medium& m = desc->media[i];
         if (m.n_boundary != 1 || desc->boundary[m.first_boundary].kind != RT_PRIM_SPHERE || placed(desc->boundary[m.first_boundary]))
             media_are_single_spheres = false;
-        media[i] = DMedium{m.first_boundary, m.n_boundary, m.neg_inv_density, m.phase_material, m.prim_id, 0u, {0, 0}, make_float4(0, 0, 0, 0)};
+        auto xform_of = [&](const rt_prim_ref& r) {
+            return r.kind == RT_PRIM_SPHERE ? desc->spheres[r.index].transform
+                 : r.kind == RT_PRIM_MOVING_SPHERE ? desc->moving_spheres[r.index].transform : desc->quads[r.index].transform;
+        };
+        uint32_t shared = m.n_boundary ? xform_of(desc->boundary[m.first_boundary]) : RT_NO_TRANSFORM;
+        for (uint32_t k = 1; k < m.n_boundary; ++k)
+            if (xform_of(desc->boundary[m.first_boundary + k]) != shared) shared = rt::XFORM_MIXED;
+        media[i] = DMedium{m.first_boundary, m.n_boundary, m.neg_inv_density, m.phase_material, m.prim_id, 0u, shared, 0u, make_float4(0, 0, 0, 0)};
         if (m.n_boundary == 1 && desc->boundary[m.first_boundary].kind == RT_PRIM_SPHERE && !placed(desc->boundary[m.first_boundary])) {
             const rt_sphere& bs = desc->spheres[desc->boundary[m.first_boundary].index];
             media[i].single_sphere = 1u;
@@ -1229,7 +1249,7 @@ static int render_rows(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, u
             if ((e = ensure_queues(c, c->pipes[i], (uint64_t)chunk_pixels * spb, n_counts, needs_overflow(sc)))) return e;
     }
     // persistent grid of the extend kernel; a preallocated overflow area bounds it for the trees that use that area
-    uint32_t extend_grid = c->counters_on ? c->extend_blocks_counting : c->extend_blocks;
+    uint32_t extend_grid = extend_grid_of(c, sc, c->counters_on);
     if (fixed && needs_overflow(sc)) extend_grid = std::min(extend_grid, NOALLOC_OVERFLOW_BLOCKS);
     DCamera dcam = to_dcamera(cam);
     DCounters* counters = c->counters_on ? c->d_counters : nullptr;
@@ -1641,7 +1661,7 @@ int rt_extend_batch(rt_scene* sc, const rt_ray* rays, size_t n, uint64_t seed, r
             if (sc->d.n_global != 0)
                 launch_first_leaves(st, c->max_blocks, group_size[bounce], sc->d, b, seed, bounce, q.counts, q.ray_o[0] + at, q.ray_d[0] + at,
                                     q.hits + at, counters);
-            launch_extend(st, counters ? c->extend_blocks_counting : c->extend_blocks, group_size[bounce], sc->d, b, seed, bounce, q.counts,
+            launch_extend(st, extend_grid_of(c, sc, counters != nullptr), group_size[bounce], sc->d, b, seed, bounce, q.counts,
                           q.ray_o[0] + at, q.ray_d[0] + at, q.hits + at, q.stack_overflow, tune, counters);
         }
         launch_unpack_hits(st, c->max_blocks, sc->d, d_rays, q.hits, n, d_hits);

@@ -62,13 +62,15 @@ RT_HD bool ref_placed(uint32_t r) { return (r & REF_PLACED) != 0; }
 // which keeps hit distances bit-identical to the reference's.  Its BVH box is
 // the world-space box of the placed leaf.
 // ---------------------------------------------------------------------------
+static constexpr uint32_t XFORM_MIXED = 0xFFFFFFFEu;  // DMedium::shared_xform: the boundary leaves do not share one placement
 struct DMedium {
     uint32_t first_boundary, n_boundary;
     float neg_inv_density;
     uint32_t phase_material;
     uint32_t prim_id;
     uint32_t single_sphere;  // 1: the boundary is one sphere in world space, repeated below (saves two dependent reads)
-    uint32_t _pad[2];
+    uint32_t shared_xform;   // the placement all boundary leaves share (RT_NO_TRANSFORM: none is placed), or XFORM_MIXED
+    uint32_t _pad;
     float4 sphere;           // centre.xyz, radius of that sphere
 };
 

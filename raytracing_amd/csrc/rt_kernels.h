@@ -40,14 +40,14 @@ struct ExtendTuning {
                           // medium in the tree is bounded by one sphere - a short test -, 24 when some boundary is a list
                           // of leaves, whose test runs to several hundred instructions)
 };
-int extend_blocks_per_cu(bool counting);
+int extend_blocks_per_cu(bool counting, bool generic_media);  // generic_media: the variant for scenes with DScene::generic_media set
 // stack levels per lane the extend kernel keeps in LDS for a tree of n_nodes nodes; deeper levels go to the overflow area
 int extend_lds_stack_levels(uint32_t n_nodes);
 size_t extend_overflow_bytes(uint32_t blocks);
 // The same computation as a pass of its own over a queue.
 void launch_first_leaves(hipStream_t st, uint32_t max_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
                          uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits, DCounters* counters);
-// resident_blocks: CUs x extend_blocks_per_cu(counters != nullptr); stack_overflow: extend_overflow_bytes(resident_blocks) bytes
+// resident_blocks: CUs x extend_blocks_per_cu(counters != nullptr, sc.generic_media); stack_overflow: extend_overflow_bytes(resident_blocks) bytes
 void launch_extend(hipStream_t st, uint32_t resident_blocks, uint32_t upper_bound, const DScene& sc, const BatchInfo& b, uint64_t seed,
                    uint32_t bounce, const uint32_t* counts, const float4* ray_o, const float4* ray_d, uint2* hits,
                    unsigned long long* stack_overflow, const ExtendTuning& tune, DCounters* counters);

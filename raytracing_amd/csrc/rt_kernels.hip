@@ -123,6 +123,28 @@ RT_D void hit_to_world(float4 rot, float4 off, float3& p, float3& n) {
     n = f3((c * n.x) + (s * n.z), n.y, (-s * n.x) + (c * n.z));
 }
 
+// A leaf against a ray that is already in the leaf's own space (object space for a placed leaf).
+template <bool COUNT>
+RT_D bool leaf_root_in_leaf_space(const DScene& sc, uint32_t ref, float3 o, float3 d, float time, float a, float tmin, float tmax, float& t, Probe& pr) {
+    const uint32_t kind = ref_kind(ref), idx = ref_index(ref);
+    if (kind != KIND_QUAD) {
+        if (COUNT) pr.spheres++;
+        float4 s;
+        float3 c;
+        if (kind == KIND_SPHERE) {
+            s = sc.spheres[idx];
+            c = f3(s);
+        } else {
+            s = sc.moving[2 * (size_t)idx];
+            c = f3(s) + time * f3(sc.moving[2 * (size_t)idx + 1]);  // MovingSphere::hit, src/hittable.rs:310
+        }
+        return sphere_root(c, s.w, o, d, a, tmin, tmax, t);
+    } else {
+        if (COUNT) pr.quads++;
+        return quad_root(sc.quads + 4 * (size_t)idx, o, d, tmin, tmax, t);
+    }
+}
+
 template <bool COUNT>
 RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float time, float a, float tmin, float tmax, float& t, Probe& pr) {
     const uint32_t kind = ref_kind(ref), idx = ref_index(ref);
@@ -154,9 +176,8 @@ RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float ti
 }
 
 // AABB::hit / AABBx2::hit (src/math/aabb.rs:32-49,127-167) for one box and the interval [lo, hi]: min / max that drop a
-// NaN, the interval as the fourth lane of the reductions.
-RT_D bool own_box_test(float4 mn, float4 mx, float3 o, float3 d, float lo, float hi) {
-    const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+// NaN, the interval as the fourth lane of the reductions.  inv = 1 / direction, component by component.
+RT_D bool own_box_test(float4 mn, float4 mx, float3 o, float3 inv, float lo, float hi) {
     const float x0 = (mn.x - o.x) * inv.x, x1 = (mx.x - o.x) * inv.x;
     const float y0 = (mn.y - o.y) * inv.y, y1 = (mx.y - o.y) * inv.y;
     const float z0 = (mn.z - o.z) * inv.z, z1 = (mx.z - o.z) * inv.z;
@@ -165,39 +186,36 @@ RT_D bool own_box_test(float4 mn, float4 mx, float3 o, float3 d, float lo, float
     return t_in <= t_out;
 }
 
-// A leaf of a medium's boundary that consists of several leaves: in the reference such a boundary is a BVH (a box is the
-// BVH of its six quads, src/hittable.rs:81-100), whose nodes test each leaf's own box - in the leaf's space, under its
-// Move / RotateY - before the leaf.  For the thin box of a quad the outcome of that test matters: far along a ray, where
-// t + 0.0001 == t, it is what keeps the second boundary query from finding the first one's quad again.
+// Closest hit of a medium's boundary object inside (lo, hi): one of the two nested queries of ConstantMediumPhase1/2
+// (src/math/ray.rs:108-128,250-265).  A boundary of one leaf is that leaf.  A boundary of several leaves is a BVH in the
+// reference (a box is the BVH of its six quads, src/hittable.rs:81-100), whose nodes test each leaf's own box - in the
+// leaf's space, under its Move / RotateY - before the leaf.  For the thin box of a quad the outcome of that test matters:
+// far along a ray, where t + 0.0001 == t, it is what keeps the second query from finding the first one's quad again.
+// The leaves of a boundary nearly always share their placement (a placed box): the ray is then taken to their space
+// once (ro, rd, ra: the ray there; rinv = 1 / rd), as the reference does on entering the Move.
 template <bool COUNT>
-RT_D bool boundary_leaf_root(const DScene& sc, uint32_t ref, const float4* __restrict__ box, float3 o, float3 d, float time, float a,
-                             float lo, float hi, float& t, Probe& pr) {
-    if (ref_placed(ref)) {
-        const uint32_t kind = ref_kind(ref), idx = ref_index(ref);
-        const float4* xf = (kind == KIND_SPHERE ? sc.sphere_xf : kind == KIND_MOVING ? sc.moving_xf : sc.quad_xf) + 2 * (size_t)idx;
-        float3 oo = o, dd = d;
-        ray_to_object(xf[0], xf[1], oo, dd);
-        if (!own_box_test(box[0], box[1], oo, dd, lo, hi)) return false;
-    } else if (!own_box_test(box[0], box[1], o, d, lo, hi)) {
-        return false;
-    }
-    return leaf_root<COUNT>(sc, ref, o, d, time, a, lo, hi, t, pr);
-}
-
-// Closest hit of a medium's boundary object inside (lo, hi): the two nested
-// queries of ConstantMediumPhase1/2 (src/math/ray.rs:108-128,250-265).
-template <bool COUNT>
-RT_D bool boundary_root(const DScene& sc, const DMedium& m, float3 o, float3 d, float time, float a, float lo, float hi, float& t,
-                        Probe& pr) {
+RT_D bool boundary_root(const DScene& sc, const DMedium& m, float3 o, float3 d, float time, float a, bool shared, float3 ro, float3 rd,
+                        float ra, float3 rinv, float lo, float hi, float& t, Probe& pr) {
+    if (m.n_boundary == 1) return leaf_root<COUNT>(sc, sc.boundary_refs[m.first_boundary], o, d, time, a, lo, hi, t, pr);
     bool any = false;
-    if (m.n_boundary == 1) {  // a lone leaf: tested directly
-        any = leaf_root<COUNT>(sc, sc.boundary_refs[m.first_boundary], o, d, time, a, lo, hi, t, pr);
-        return any;
-    }
     for (uint32_t i = 0; i < m.n_boundary; ++i) {
-        uint32_t ref = sc.boundary_refs[m.first_boundary + i];
+        const uint32_t ref = sc.boundary_refs[m.first_boundary + i];
+        const float4* box = sc.boundary_boxes + 2 * (size_t)(m.first_boundary + i);
         float tt;
-        if (boundary_leaf_root<COUNT>(sc, ref, sc.boundary_boxes + 2 * (size_t)(m.first_boundary + i), o, d, time, a, lo, hi, tt, pr)) {
+        bool hit;
+        if (shared) {
+            hit = own_box_test(box[0], box[1], ro, rinv, lo, hi) && leaf_root_in_leaf_space<COUNT>(sc, ref, ro, rd, time, ra, lo, hi, tt, pr);
+        } else {
+            float3 oo = o, dd = d;
+            if (ref_placed(ref)) {
+                const uint32_t kind = ref_kind(ref), idx = ref_index(ref);
+                const float4* xf = (kind == KIND_SPHERE ? sc.sphere_xf : kind == KIND_MOVING ? sc.moving_xf : sc.quad_xf) + 2 * (size_t)idx;
+                ray_to_object(xf[0], xf[1], oo, dd);
+            }
+            hit = own_box_test(box[0], box[1], oo, f3(1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z), lo, hi) &&
+                  leaf_root<COUNT>(sc, ref, o, d, time, a, lo, hi, tt, pr);
+        }
+        if (hit) {
             any = true;
             hi = tt;
         }
@@ -275,8 +293,18 @@ RT_D bool medium_root(const DScene& sc, uint32_t idx, float3 o, float3 d, float 
         if (!sphere_roots(f3(m.sphere), m.sphere.w, o, d, a, near_root, far_root)) return false;
         if (!medium_span_of_roots(near_root, far_root, t1, t2)) return false;
     } else {
-        if (!boundary_root<COUNT>(sc, m, o, d, time, a, -RT_INF, RT_INF, t1, pr)) return false;
-        if (!boundary_root<COUNT>(sc, m, o, d, time, a, 0.0001f + t1, RT_INF, t2, pr)) return false;
+        const bool shared = m.n_boundary > 1 && m.shared_xform != XFORM_MIXED;
+        float3 ro = o, rd = d, rinv = o;
+        float ra = a;
+        if (shared) {
+            if (m.shared_xform != REF_NONE) {  // REF_NONE = 0xFFFFFFFF: no placement
+                ray_to_object(sc.xforms[2 * (size_t)m.shared_xform], sc.xforms[2 * (size_t)m.shared_xform + 1], ro, rd);
+                ra = dot3(rd, rd);
+            }
+            rinv = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        }
+        if (!boundary_root<COUNT>(sc, m, o, d, time, a, shared, ro, rd, ra, rinv, -RT_INF, RT_INF, t1, pr)) return false;
+        if (!boundary_root<COUNT>(sc, m, o, d, time, a, shared, ro, rd, ra, rinv, 0.0001f + t1, RT_INF, t2, pr)) return false;
     }
     return medium_sample(m, idx, t1, t2, a, tmin, tmax, key, t);
 }
@@ -1094,7 +1122,7 @@ static constexpr int OVERFLOW_STACK = STACK_SIZE - MIN_LDS_STACK;
 #define RT_EXTEND_WAVES 6  // resident waves per SIMD the register allocation aims for
 #endif
 template <bool COUNT, bool SMALL_TREE, bool GENERIC>
-__global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_EXTEND_WAVES, RT_EXTEND_WAVES))) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
+__global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GENERIC ? RT_EXTEND_WAVES - 1 : RT_EXTEND_WAVES, GENERIC ? RT_EXTEND_WAVES - 1 : RT_EXTEND_WAVES))) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                          const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
                                                          const float4* __restrict__ ray_d, uint2* __restrict__ hits,
                                                          unsigned long long* __restrict__ stack_overflow, ExtendTuning tune,
@@ -1754,20 +1782,20 @@ void launch_primary_rays(hipStream_t st, uint32_t max_blocks, const DCamera& cam
 // kernel's registers, LDS and scratch.  The persistent grid must not exceed CUs x this number:
 // blocks beyond it only start when earlier ones have finished, and then work their interleaved
 // share of the queue on an almost empty chip.
-int extend_blocks_per_cu(bool counting) {
+int extend_blocks_per_cu(bool counting, bool generic_media) {
     int a = 0;
-    // the smallest figure over the variants of the kernel (large / small tree, with / without the code for media of any boundary)
+    // the smaller figure of the two variants (large / small tree) a scene of this kind can get
     auto blocks_of = [](auto kernel) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, EXTEND_BLOCK, 0) != hipSuccess) n = 0;
         return n;
     };
-    if (counting)
-        a = std::min(std::min(blocks_of(k_extend<true, false, false>), blocks_of(k_extend<true, true, false>)),
-                     std::min(blocks_of(k_extend<true, false, true>), blocks_of(k_extend<true, true, true>)));
+    if (generic_media)
+        a = counting ? std::min(blocks_of(k_extend<true, false, true>), blocks_of(k_extend<true, true, true>))
+                     : std::min(blocks_of(k_extend<false, false, true>), blocks_of(k_extend<false, true, true>));
     else
-        a = std::min(std::min(blocks_of(k_extend<false, false, false>), blocks_of(k_extend<false, true, false>)),
-                     std::min(blocks_of(k_extend<false, false, true>), blocks_of(k_extend<false, true, true>)));
+        a = counting ? std::min(blocks_of(k_extend<true, false, false>), blocks_of(k_extend<true, true, false>))
+                     : std::min(blocks_of(k_extend<false, false, false>), blocks_of(k_extend<false, true, false>));
     (void)hipGetLastError();
     // a block whose LDS divides the CU's 160 KiB exactly does not get the last slot in practice
     int by_lds = (int)((160u * 1024u - 1024u) / (2048u * (uint32_t)RT_EXTEND_STACK + 16u));  // 2 KiB per stack level and block

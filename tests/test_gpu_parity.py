@@ -1141,6 +1141,58 @@ def test_origins_near_the_faces_of_the_boxes_of_leaves_tested_ahead_of_the_tree(
     assert (np.abs(got["t"][hit] - want["t"][hit]) <= 1e-5 * np.maximum(1.0, np.abs(want["t"][hit]))).all()
 
 
+def _far_box_media(s, placed):
+    t = s.tex_solid(0.6, 0.6, 0.7)
+    lam = s.lambertian(t)
+    items = []
+    for half, dens in ((700.0, 1.5e-4), (746.15, 1.9e-4), (530.9, 4e-4)):
+        box = s.box((-half,) * 3, (half,) * 3, lam)
+        if placed:
+            box = s.move(s.rotate_y(box, 15.0), (20.0, -10.0, 5.0))
+        items.append(s.medium(box, dens, t))
+    items.append(s.medium(s.moving_sphere((-60, 50, 90), (2, 110, 150), 730.0, lam), 2.7e-4, t))
+    for i in range(7):
+        items.append(s.sphere((250.0 - 80 * i, 40.0 * i - 100, 30.0 * i), 20.0 + 5 * i, lam))
+    s.set_world(s.bvh(items))
+    s.camera((0, 0, -300), 32, 32, max_depth=4, vfov=60.0, background=(0.7, 0.8, 0.9), yaw=90.0)
+    return s
+
+
+@pytest.mark.parametrize("placed", [False, True], ids=["in_world_space", "under_move_and_rotate"])
+def test_box_bounded_media_far_along_a_ray(placed):
+    """ConstantMedium's second boundary query starts at t1 + 0.0001 (src/math/ray.rs:108-128).  Beyond |t1| = 2048 that sum
+    is t1 again, Quad::hit's interval is closed (src/hittable.rs:372-398), so the query meets the quad of the first one again -
+    unless the BVH over the box's six quads (src/hittable.rs:81-100) drops that quad first: its own thin box
+    (AABB::pad_to_minimums, src/math/aabb.rs:79-98) is tested against the interval, and passes or fails by a rounding.
+    Whether a medium is seen at all then hangs on that box test, so the kernels make it too, leaf by leaf, in the leaf's
+    space.  Short direction vectors put every boundary thousands of units of t away."""
+    gpu, cpu = _far_box_media(rt.Scene(), placed), _far_box_media(ob.OracleScene(), placed)
+    rng = np.random.default_rng(41)
+    n = 60000
+    rays = np.zeros(n, _abi.ray_dtype())
+    rays["origin"] = rng.uniform(-900, 900, (n, 3))
+    rays["direction"] = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-3, 0.5, (n, 1))
+    rays["time"] = rng.uniform(0, 1, n)
+    rays["tmin"], rays["tmax"] = 0.001, np.inf
+    rays["rng_pixel"], rays["rng_sample"], rays["rng_bounce"] = np.arange(n) % 4096, 1 + np.arange(n) // 4096, rng.integers(0, 4, n)
+    want = cpu.intersect(rays, seed=41)
+    a, b = gpu.intersect(rays, seed=41), gpu.extend(rays, seed=41)
+    _same_records(a, b)
+    hit = want["hit"] == 1
+    if placed:
+        # (origin - offset) + offset need not be the origin again (src/math/ray.rs:75-84): the reference tests the leaves
+        # after a Move with an origin an ulp off, which moves a box test's rounding now and then
+        assert (a["hit"] == want["hit"]).mean() >= 0.9995
+        hit &= a["hit"] == 1
+        assert (a["prim_id"][hit] == want["prim_id"][hit]).mean() >= 0.999
+        hit &= a["prim_id"] == want["prim_id"]
+    else:
+        assert np.array_equal(a["hit"], want["hit"])
+        assert np.array_equal(a["prim_id"][hit], want["prim_id"][hit])
+    assert 0.1 < hit.mean() < 0.9
+    assert (np.abs(a["t"][hit] - want["t"][hit]) <= 2e-5 * np.maximum(1.0, np.abs(want["t"][hit]))).all()
+
+
 def test_extend_kernel_rejects_rays_the_render_path_never_casts():
     s = rt.Scene.builtin(6, 16, 16)
     rays = s.primary_rays(np.arange(4, dtype=np.uint32), 1)
