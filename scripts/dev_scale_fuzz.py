@@ -1,0 +1,96 @@
+"""Random scenes of every leaf kind (spheres, moving spheres, quads, boxes and spheres under Move{RotateY}, media bounded by
+boxes, spheres and moving spheres) at scales 1e-3 ... 1e4 with direction vectors of lengths 1e-4 ... 1e4: both traversals per
+ray against the oracle.  SEEDS=a,b,c selects the seeds; DETAIL=1 prints the first mismatching rays."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_binding as ob
+import raytracing_amd as rt
+from raytracing_amd import _abi
+
+
+def scene(s, rng):
+    t = s.tex_solid(0.6, 0.6, 0.7)
+    lam, glass = s.lambertian(t), s.dielectric(t, 1.5)
+    S = float(10.0 ** rng.uniform(-3, 4))
+    items = []
+    for i in range(int(rng.integers(8, 60))):
+        c = rng.uniform(-6, 6, 3) * S
+        kind = int(rng.integers(0, 8))
+        m = lam if rng.random() < 0.7 else glass
+        if kind == 0:
+            items.append(s.sphere(c, float(rng.uniform(0.2, 1.5) * S), m))
+        elif kind == 1:
+            items.append(s.moving_sphere(c, c + rng.uniform(-0.5, 0.5, 3) * S, float(rng.uniform(0.2, 0.8) * S), m))
+        elif kind == 2:
+            items.append(s.quad(c, rng.uniform(-2, 2, 3) * S, rng.uniform(-2, 2, 3) * S, m))
+        elif kind == 3:
+            items.append(s.box(c, c + rng.uniform(0.3, 2, 3) * S, m))
+        elif kind == 4:
+            b = s.box((0, 0, 0), rng.uniform(0.5, 2, 3) * S, m)
+            items.append(s.move(s.rotate_y(b, float(rng.uniform(-180, 180))), c))
+        elif kind == 5:
+            sp = s.sphere(rng.uniform(-1, 1, 3) * S, float(rng.uniform(0.3, 1.0) * S), m)
+            items.append(s.move(s.rotate_y(sp, float(rng.uniform(-90, 90))), c))
+        elif kind == 6:
+            which = int(rng.integers(0, 3))
+            if which == 0:
+                bd = s.box(c, c + rng.uniform(0.5, 3, 3) * S, lam)
+            elif which == 1:
+                bd = s.sphere(c, float(rng.uniform(0.5, 2) * S), lam)
+            else:
+                bd = s.moving_sphere(c, c + rng.uniform(-0.5, 0.5, 3) * S, float(rng.uniform(0.5, 1.5) * S), lam)
+            items.append(s.medium(bd, float(rng.uniform(0.05, 2.0) / S), t))
+        else:
+            b = s.box((0, 0, 0), rng.uniform(0.5, 2, 3) * S, lam)
+            items.append(s.medium(s.move(s.rotate_y(b, float(rng.uniform(-180, 180))), c), float(rng.uniform(0.05, 2.0) / S), t))
+    s.set_world(s.bvh(items))
+    s.camera((0, 0, -14 * S), 32, 32, max_depth=4, vfov=50.0, background=(0.3, 0.4, 0.5), yaw=90.0)
+    return s, S
+
+
+bad = 0
+for seed in [int(x) for x in os.environ.get("SEEDS", ",".join(str(i) for i in range(40))).split(",")]:
+    (gpu, S), (cpu, _) = scene(rt.Scene(), np.random.default_rng(seed)), scene(ob.OracleScene(), np.random.default_rng(seed))
+    rng = np.random.default_rng(seed + 5000)
+    n = 20000
+    rays = np.zeros(n, _abi.ray_dtype())
+    rays["origin"] = rng.uniform(-8, 8, (n, 3)) * S
+    rays["direction"] = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-4, 4, (n, 1))
+    rays["time"] = rng.uniform(0, 1, n)
+    rays["tmin"], rays["tmax"] = 0.001, np.inf
+    rays["rng_pixel"], rays["rng_sample"], rays["rng_bounce"] = np.arange(n) % 4096, 1 + np.arange(n) // 4096, rng.integers(0, 4, n)
+    want = cpu.intersect(rays, seed=seed)
+    a, b = gpu.intersect(rays, seed=seed), gpu.extend(rays, seed=seed)
+    same_ab = a["t"].tobytes() == b["t"].tobytes() and a["prim_id"].tobytes() == b["prim_id"].tobytes()
+    hit = (want["hit"] == 1) & (a["hit"] == 1)
+    with np.errstate(all="ignore"):
+        rel = np.abs(a["t"] - want["t"]) / np.maximum(np.abs(want["t"]), 1e-30)
+    same_prim = hit & (a["prim_id"] == want["prim_id"])
+    tie = hit & ~same_prim & (rel <= 1e-5)
+    # Excused: (1) a medium far along the ray on either side (|t| >= 2048: there t + 0.0001 == t and whether a box-bounded
+    # medium is seen hangs on roundings of thin-box tests in the order of the reference's own tree); (2) t within 1e-4 on the
+    # same leaf (leaves under a Move: the reference's origin drifts by an ulp after each Move, src/math/ray.rs:75-84, which
+    # cancellation amplifies for hits close to the origin or very far from it).
+    is_medium = lambda h: (h["hit"] == 1) & (np.abs(h["normal"] - np.array([1, 0, 0], np.float32)).max(axis=1) == 0)
+    far = np.maximum(np.where(a["hit"] == 1, np.abs(a["t"]), 0), np.where(want["hit"] == 1, np.abs(want["t"]), 0)) >= 2048
+    far_medium = (is_medium(a) | is_medium(want)) & far
+    wrong_flag = (a["hit"] != want["hit"]) & ~far_medium
+    wrong_prim = hit & ~same_prim & ~tie & ~far_medium
+    wrong_t = same_prim & (rel > 1e-4)
+    n_flag, n_prim, n_t = int(wrong_flag.sum()), int(wrong_prim.sum()), int(wrong_t.sum())
+    n_far, n_loose = int((far_medium & ((a["hit"] != want["hit"]) | (hit & ~same_prim & ~tie))).sum()), int((same_prim & (rel > 2e-5) & ~wrong_t).sum())
+    good = same_ab and n_flag == 0 and n_prim == 0 and n_t == 0
+    bad += not good
+    print(f"seed {seed:4d} S {S:9.3g} leaves {gpu.info()['leaves_in_tree']}+{gpu.info()['leaves_tested_first']} hit {hit.mean():.2f} a==b {same_ab} "
+          f"flag {n_flag} prim {n_prim} ties {int(tie.sum())} t {n_t} far-medium {n_far} t-within-1e-4 {n_loose} "
+          f"exact {int((a['t'][same_prim] == want['t'][same_prim]).sum())}/{int(same_prim.sum())} {'ok' if good else 'FAILED'}", flush=True)
+    if not good and os.environ.get("DETAIL"):
+        idx = np.nonzero(wrong_flag | wrong_prim | wrong_t)[0]
+        for i in idx[:4]:
+            print("  ray", i, "o", rays["origin"][i], "d", rays["direction"][i], "time", rays["time"][i], "bounce", rays["rng_bounce"][i])
+            print("    want hit", want["hit"][i], "prim", want["prim_id"][i], "t", want["t"][i], "mat", want["material"][i], "n", want["normal"][i],
+                  "| got hit", a["hit"][i], "prim", a["prim_id"][i], "t", a["t"][i], "mat", a["material"][i], "n", a["normal"][i])
+print("failures:", bad)
+sys.exit(1 if bad else 0)
