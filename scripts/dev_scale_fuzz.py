@@ -14,11 +14,19 @@ def scene(s, rng):
     t = s.tex_solid(0.6, 0.6, 0.7)
     lam, glass = s.lambertian(t), s.dielectric(t, 1.5)
     S = float(10.0 ** rng.uniform(-3, 4))
+    # every material and texture kind (the shading of the hits is compared too)
+    tex = [t, s.tex_solid(*rng.uniform(0.1, 0.9, 3))]
+    tex.append(s.tex_checker(float(rng.uniform(0.1, 3) * S), tex[0], tex[1]))
+    tex.append(s.tex_noise(s.perlin((5, 6, 7, 8), int(rng.integers(2, 257))), float(rng.uniform(0.1, 4) / S)))
+    tex.append(s.tex_image(rng.integers(0, 256, (int(rng.integers(1, 9)), int(rng.integers(1, 9)), 3), dtype=np.uint8)))
+    tex.append(s.tex_checker(float(rng.uniform(0.1, 3) * S), tex[2], tex[3]))
+    mats = [lam, glass] + [s.lambertian(x) for x in tex[1:]] + [s.metal(tex[int(rng.integers(len(tex)))], float(rng.uniform(0, 1.5))),
+            s.dielectric(tex[1], float(rng.uniform(0.3, 2.5))), s.diffuse_light(tex[int(rng.integers(len(tex)))]), s.isotropic(tex[int(rng.integers(len(tex)))])]
     items = []
     for i in range(int(rng.integers(8, 60))):
         c = rng.uniform(-6, 6, 3) * S
         kind = int(rng.integers(0, 8))
-        m = lam if rng.random() < 0.7 else glass
+        m = mats[int(rng.integers(len(mats)))]
         if kind == 0:
             items.append(s.sphere(c, float(rng.uniform(0.2, 1.5) * S), m))
         elif kind == 1:
@@ -86,6 +94,35 @@ for seed in [int(x) for x in os.environ.get("SEEDS", ",".join(str(i) for i in ra
     print(f"seed {seed:4d} S {S:9.3g} leaves {gpu.info()['leaves_in_tree']}+{gpu.info()['leaves_tested_first']} hit {hit.mean():.2f} a==b {same_ab} "
           f"flag {n_flag} prim {n_prim} ties {int(tie.sum())} t {n_t} far-medium {n_far} t-within-1e-4 {n_loose} "
           f"exact {int((a['t'][same_prim] == want['t'][same_prim]).sum())}/{int(same_prim.sum())} {'ok' if good else 'FAILED'}", flush=True)
+    # Material::scatter / emitted / Texture::value on the oracle's hits
+    keep = want["hit"] == 1
+    if keep.any():
+        sc_c, att_c, em_c = cpu.shade(rays[keep], want[keep], seed=seed)
+        sc_g, att_g, em_g = gpu.shade(rays[keep], want[keep], seed=seed)
+        with np.errstate(all="ignore"):
+            size = np.maximum(1e-30, np.abs(sc_c["direction"]).max(axis=1, keepdims=True))
+            d_err = np.nan_to_num(np.abs(sc_g["direction"] - sc_c["direction"]) / size).max(axis=1)
+            shade_bad = (sc_g["tmin"] != sc_c["tmin"]) | (d_err > 1e-5) | (np.isnan(sc_g["direction"]) != np.isnan(sc_c["direction"])).any(axis=1) | \
+                        (np.abs(np.nan_to_num(att_g - att_c)).max(axis=1) > 1e-5) | (np.isnan(att_g) != np.isnan(att_c)).any(axis=1) | \
+                        (np.abs(np.nan_to_num(em_g - em_c)).max(axis=1) > 1e-5) | ~(sc_g["origin"] == sc_c["origin"]).all(axis=1)
+        if shade_bad.any():
+            bad += 1
+            j = np.nonzero(shade_bad)[0]
+            print(f"  seed {seed}: shading differs on {len(j)} of {int(keep.sum())} hits FAILED", flush=True)
+            for i in j[:3]:
+                print("    hit mat", want[keep]["material"][i], "p", want[keep]["point"][i], "uv", want[keep]["u"][i], want[keep]["v"][i], "| dir", sc_c["direction"][i], sc_g["direction"][i],
+                      "att", att_c[i], att_g[i], "emit", em_c[i], em_g[i], "tmin", sc_c["tmin"][i], sc_g["tmin"][i])
+    if os.environ.get("RENDER"):  # the whole path: a small image with shared random numbers, pixel by pixel
+        spp = 4
+        gpu.set_seed(seed)
+        gpu.render_samples(spp)
+        got, ref = gpu.accumulator(), cpu.render(spp, seed=seed)
+        with np.errstate(all="ignore"):
+            close = np.all(np.abs(got[..., :3] - ref[..., :3]) <= 1e-4 * np.maximum(1.0, np.abs(ref[..., :3])), axis=-1) | \
+                    np.all(np.isnan(got[..., :3]) & np.isnan(ref[..., :3]), axis=-1)
+        print(f"  seed {seed}: image {close.mean():.4f} of the pixels within 1e-4, finite {np.isfinite(got).mean():.4f} / {np.isfinite(ref).mean():.4f}"
+              f"{'' if close.mean() >= 0.97 else ' FAILED'}", flush=True)
+        bad += close.mean() < 0.97
     if not good and os.environ.get("DETAIL"):
         idx = np.nonzero(wrong_flag | wrong_prim | wrong_t)[0]
         for i in idx[:4]:
