@@ -941,6 +941,22 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
         bp.exact = (w.kind != RT_PRIM_MEDIUM && !placed(w)) ? 1u : 0u;
         prims.push_back(bp);
     }
+    // Rays start at the camera or on a leaf.  Where all the leaves of the tree lie inside the box of a sphere that is tested
+    // first, nearly every ray starts inside that box and its box test can be decided without a division (sphere_box_test in
+    // the kernels tries that first); where they do not (a ground sphere below the scene), trying would be wasted work.
+    uint32_t global_inside = 0;
+    {
+        Aabb rest;
+        for (const BuildPrim& bp : prims)
+            for (int a = 0; a < 3; ++a) { rest.mn[a] = std::min(rest.mn[a], bp.bmin[a]); rest.mx[a] = std::max(rest.mx[a], bp.bmax[a]); }
+        for (uint32_t g = 0; g < n_global; ++g) {
+            if (ref_kind(global_refs[g]) != KIND_SPHERE) continue;
+            const Aabb& b = sphere_box[ref_index(global_refs[g])];
+            bool inside = !prims.empty();
+            for (int a = 0; a < 3; ++a) inside = inside && b.mn[a] <= rest.mn[a] && rest.mx[a] <= b.mx[a];
+            if (inside) global_inside |= 1u << g;
+        }
+    }
     FlatBvh bvh = build_bvh(prims, 0);
     if (bvh.stack_need > rt::TRAVERSAL_STACK_ENTRIES)
         return fail(RT_ERR_UNSUPPORTED, "the tree (depth %u) can need %u traversal stack entries, %u are available", bvh.max_depth,
@@ -1094,6 +1110,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     sc->info.leaves_tested_first = n_global;
     sc->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     sc->d.n_global = n_global;
+    sc->d.global_inside = global_inside;
     {
         std::vector<uint32_t> g(global_refs, global_refs + 7);
         if ((e = upload(sc, g, &sc->d.global_refs))) return bail(e);

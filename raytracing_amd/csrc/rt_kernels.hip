@@ -512,12 +512,13 @@ RT_D uint32_t leaf_step(const DScene& sc, const TravRay& r, uint32_t cur, float&
 // tested as src/math/aabb.rs:127-167 tests it).  When the origin lies inside the box, at least 2 tmin |d_k| from
 // every face, the test passes whatever the rounding: each entry distance is negative, each exit distance is
 // at least 2 tmin (1 - 2^-22) >= tmin (tmin >= 0), so the interval is [tmin, min(exits, tmax)] and not empty.  That case
-// needs no division; every other ray takes the test itself.
-RT_D bool sphere_box_test(float4 s, const TravRay& r, float tmax) {
+// needs no division; every other ray takes the test itself.  try_inside: whether rays of this scene start inside the box
+// as a rule (decided per scene: the attempt costs twenty instructions).
+RT_D bool sphere_box_test(float4 s, const TravRay& r, float tmax, bool try_inside) {
     const float3 lo = f3(s.x - s.w, s.y - s.w, s.z - s.w), hi = f3(s.x + s.w, s.y + s.w, s.z + s.w);
     const float m = fminf(fminf(fminf(r.o.x - lo.x, hi.x - r.o.x), fminf(r.o.y - lo.y, hi.y - r.o.y)), fminf(r.o.z - lo.z, hi.z - r.o.z));
     const float two_tmin = 2.0f * r.tmin;
-    if (m > 0.0f && m >= two_tmin * fabsf(r.d.x) && m >= two_tmin * fabsf(r.d.y) && m >= two_tmin * fabsf(r.d.z) && 0.0f <= r.tmin && r.tmin <= tmax)
+    if (try_inside && m > 0.0f && m >= two_tmin * fabsf(r.d.x) && m >= two_tmin * fabsf(r.d.y) && m >= two_tmin * fabsf(r.d.z) && 0.0f <= r.tmin && r.tmin <= tmax)
         return true;
     const float3 inv = f3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     float x0 = (lo.x - r.o.x) * inv.x, x1 = (hi.x - r.o.x) * inv.x;
@@ -557,7 +558,7 @@ RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_
                             root = far_root;
                             in = r.tmin < root && root < tmax;
                         }
-                        if (in && sphere_box_test(s, r, tmax)) {
+                        if (in && sphere_box_test(s, r, tmax, (sc.global_inside >> g) & 1u)) {
                             tmax = root;
                             best = ref;
                         }
@@ -572,7 +573,7 @@ RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_
                     continue;
                 }
             }
-            hit = sphere_box_test(s, r, tmax) && leaf_root<COUNT>(sc, ref, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr);
+            hit = sphere_box_test(s, r, tmax, (sc.global_inside >> g) & 1u) && leaf_root<COUNT>(sc, ref, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr);
         }
         if (hit) {
             tmax = t;
@@ -601,13 +602,13 @@ RT_D uint2 first_leaves_hit(const DScene& sc, const BatchInfo& b, uint64_t seed,
 // reference (REF_NONE on a miss) and its t.
 // ---------------------------------------------------------------------------
 // The tree walk of one ray from start to finish by one thread: improves (tmax, best).
-template <bool COUNT, class Stack, class Key>
+template <bool COUNT, bool GENERIC, class Stack, class Key>
 RT_D void walk_tree(const DScene& sc, const TravRay& r, float& tmax, uint32_t& best, const Key& key, Stack& st, Probe& pr) {
     const NodeSource src{sc.nodes, nullptr, 0};
     uint32_t cur = sc.root == REF_NONE ? REF_DONE : sc.root;
     while (cur != REF_DONE) {
         if (!ref_is_leaf(cur)) cur = node_step<COUNT, false>(src, r, cur, tmax, st, pr);
-        else cur = leaf_step<COUNT, true>(sc, r, cur, tmax, best, key, st, pr);
+        else cur = leaf_step<COUNT, GENERIC>(sc, r, cur, tmax, best, key, st, pr);
     }
 }
 
@@ -618,7 +619,7 @@ RT_D uint32_t closest_hit(const DScene& sc, float3 o, float3 d, float time, floa
     TravRay r = make_trav_ray(o, d, time, tmin);
     global_leaves<COUNT, true>(sc, r, tmax, best, key, pr);
     PrivateStack st;
-    walk_tree<COUNT>(sc, r, tmax, best, key, st, pr);
+    walk_tree<COUNT, true>(sc, r, tmax, best, key, st, pr);
     t_hit = tmax;
     return best;
 }
@@ -1556,6 +1557,7 @@ static constexpr int TAIL_BLOCK = 256;
 // every part of a bounce, and runs the code of every material class its lanes have hit one after the other, so the time
 // of a bounce grows with the number of lanes in use; the kernel's time is that of its longest path, bounce after bounce.
 // A lane whose path has ended takes the wave's next ray, if there is one.
+template <bool GENERIC>
 __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t first_bounce,
                                                      const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
                                                      const float4* __restrict__ ray_d, const float* __restrict__ thr,
@@ -1588,9 +1590,9 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(DScene sc, DCamera cam, Bat
             const TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
             float tmax = RT_INF;
             uint32_t best = REF_NONE;
-            global_leaves<false, true>(sc, r, tmax, best, key, pr);
+            global_leaves<false, GENERIC>(sc, r, tmax, best, key, pr);
             st.sp = 0;
-            walk_tree<false>(sc, r, tmax, best, key, st, pr);
+            walk_tree<false, GENERIC>(sc, r, tmax, best, key, st, pr);
             float4 no, nd, nt;
             // (shade_one ends the path - and writes its radiance - at a miss, a light, an absorbed ray or the depth limit)
             have = shade_one<true, true>(sc, cam, b, seed, bounce, ro, rd, th, make_uint2(__float_as_uint(tmax), best), radiance, no, nd, nt);
@@ -1803,7 +1805,10 @@ int extend_blocks_per_cu(bool counting, bool generic_media) {
 }
 int tail_blocks_per_cu() {
     int a = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_tail, TAIL_BLOCK, 0) != hipSuccess) a = 0;
+    int g = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_tail<false>, TAIL_BLOCK, 0) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&g, k_tail<true>, TAIL_BLOCK, 0) != hipSuccess) g = 0;
+    a = std::min(a, g);
     (void)hipGetLastError();
     return a;
 }
@@ -1851,7 +1856,7 @@ void launch_tail(hipStream_t st, uint32_t resident_blocks, uint32_t upper_bound,
     // as many waves as the chip holds, unless there are fewer rays than that (the fewer lanes of a wave have a ray, the
     // shorter its bounce)
     const uint32_t blocks = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(((unsigned long long)upper_bound + 3ull) / 4ull, 1ull), resident_blocks);
-    hipLaunchKernelGGL(k_tail, dim3(blocks), dim3(TAIL_BLOCK), 0, st, sc, cam, b, seed, first_bounce, counts, ray_o,
+    hipLaunchKernelGGL(sc.generic_media ? k_tail<true> : k_tail<false>, dim3(blocks), dim3(TAIL_BLOCK), 0, st, sc, cam, b, seed, first_bounce, counts, ray_o,
                        ray_d, thr, radiance, stack_overflow);
 }
 
