@@ -1104,6 +1104,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     for (const std::vector<uint4>* metas : {&sphere_meta, &moving_meta, &quad_meta, &medium_meta})
         for (size_t i = 0; i < metas->size(); i += 2)
             if (((*metas)[i].w & 0xFFu) == CLS_TEXTURED) sc->has_textures = true;
+    sc->d.textured = sc->has_textures ? 1u : 0u;
     sc->info.bvh_nodes = bvh.n_nodes;
     sc->info.bvh_depth = bvh.max_depth;
     sc->info.leaves_in_tree = (uint32_t)prims.size();

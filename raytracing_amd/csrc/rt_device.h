@@ -145,6 +145,7 @@ struct DScene {
     uint32_t n_global;         // leaves kept out of the tree: tested first for every ray
     uint32_t global_inside;    // bit g: the tree's leaves all lie inside the box of global_refs[g] (a sphere): rays start inside that box
     uint32_t lds_perlin;       // 1: the scene has exactly one noise table and it fits the textured-shade kernel's LDS copy
+    uint32_t textured;         // 1: some leaf's hits are of the textured shading class
     uint32_t generic_media;    // 1: some medium's boundary is not one sphere in world space (selects the kernels that hold the code for those)
     const uint32_t* global_refs;  // n_global leaf references tested ahead of the tree
 };

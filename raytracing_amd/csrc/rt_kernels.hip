@@ -1557,7 +1557,9 @@ static constexpr int TAIL_BLOCK = 256;
 // every part of a bounce, and runs the code of every material class its lanes have hit one after the other, so the time
 // of a bounce grows with the number of lanes in use; the kernel's time is that of its longest path, bounce after bounce.
 // A lane whose path has ended takes the wave's next ray, if there is one.
-template <bool GENERIC>
+// GENERIC: as for k_extend; TEXTURES: the scene has hits of the textured class (image, noise, nested checkers).  The kernel
+// waits for its own instruction stream more than for anything else, so a scene gets the variant with no more code than it needs.
+template <bool GENERIC, bool TEXTURES>
 __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(DScene sc, DCamera cam, BatchInfo b, uint64_t seed, uint32_t first_bounce,
                                                      const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
                                                      const float4* __restrict__ ray_d, const float* __restrict__ thr,
@@ -1595,7 +1597,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(DScene sc, DCamera cam, Bat
             walk_tree<false, GENERIC>(sc, r, tmax, best, key, st, pr);
             float4 no, nd, nt;
             // (shade_one ends the path - and writes its radiance - at a miss, a light, an absorbed ray or the depth limit)
-            have = shade_one<true, true>(sc, cam, b, seed, bounce, ro, rd, th, make_uint2(__float_as_uint(tmax), best), radiance, no, nd, nt);
+            have = shade_one<TEXTURES, true>(sc, cam, b, seed, bounce, ro, rd, th, make_uint2(__float_as_uint(tmax), best), radiance, no, nd, nt);
             ro = no; rd = nd; th = nt;
             ++bounce;
         }
@@ -1805,10 +1807,12 @@ int extend_blocks_per_cu(bool counting, bool generic_media) {
 }
 int tail_blocks_per_cu() {
     int a = 0;
-    int g = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_tail<false>, TAIL_BLOCK, 0) != hipSuccess) a = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&g, k_tail<true>, TAIL_BLOCK, 0) != hipSuccess) g = 0;
-    a = std::min(a, g);
+    a = 1 << 30;
+    for (auto kernel : {k_tail<false, false>, k_tail<false, true>, k_tail<true, false>, k_tail<true, true>}) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, TAIL_BLOCK, 0) != hipSuccess) n = 0;
+        a = std::min(a, n);
+    }
     (void)hipGetLastError();
     return a;
 }
@@ -1856,7 +1860,8 @@ void launch_tail(hipStream_t st, uint32_t resident_blocks, uint32_t upper_bound,
     // as many waves as the chip holds, unless there are fewer rays than that (the fewer lanes of a wave have a ray, the
     // shorter its bounce)
     const uint32_t blocks = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(((unsigned long long)upper_bound + 3ull) / 4ull, 1ull), resident_blocks);
-    hipLaunchKernelGGL(sc.generic_media ? k_tail<true> : k_tail<false>, dim3(blocks), dim3(TAIL_BLOCK), 0, st, sc, cam, b, seed, first_bounce, counts, ray_o,
+    auto kernel = sc.generic_media ? (sc.textured ? k_tail<true, true> : k_tail<true, false>) : (sc.textured ? k_tail<false, true> : k_tail<false, false>);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(TAIL_BLOCK), 0, st, sc, cam, b, seed, first_bounce, counts, ray_o,
                        ray_d, thr, radiance, stack_overflow);
 }
 
