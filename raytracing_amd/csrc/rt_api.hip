@@ -977,7 +977,7 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
             for (int k = 0; ok && k < rt::BVH_WIDTH; ++k) {
                 uint32_t r;
                 std::memcpy(&r, &bvh.nodes[rt::NODE_FLOATS * (size_t)i + rt::NODE_REFS_AT + k], 4);
-                const bool empty_slot = bvh.nodes[rt::NODE_FLOATS * (size_t)i + rt::NODE_SLACK_AT + k] == 0.0f;
+                const bool empty_slot = !(bvh.nodes[rt::NODE_FLOATS * (size_t)i + rt::NODE_SLACK_AT + k] > 0.0f);
                 ok = empty_slot || ref_ok(r);
             }
         }
@@ -1172,7 +1172,7 @@ int rt_bvh_build_check(const float* boxes, uint32_t n, rt_bvh_report* out) {
         if (node_seen[it.node]++) { ++violations; continue; }
         for (int k = 0; k < rt::BVH_WIDTH; ++k) {
             const float slack = bvh.nodes[rt::NODE_FLOATS * (size_t)it.node + rt::NODE_SLACK_AT + k];
-            if (slack == 0.0f) continue;  // empty slot
+            if (!(slack > 0.0f)) continue;  // empty slot (NaN)
             uint32_t r;
             std::memcpy(&r, &bvh.nodes[rt::NODE_FLOATS * (size_t)it.node + rt::NODE_REFS_AT + k], 4);
             Box3 cb = child_box(it.node, k);

@@ -10,6 +10,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <thread>
 
 namespace rt {
@@ -161,7 +162,8 @@ struct Builder {
 // whichever way gives the whole tree the least summed box surface of its nodes.  Boxes, references and slack factors
 // are copied unchanged, so what is tested for a leaf does not depend on the width.
 // Wide node (32 floats): child k's min.x min.y max.x max.y at 4k; z ranges (min, max) at 16 + 2k;
-// references at 24 + k; slack at 28 + k (0 marks an empty slot: such a child is never entered).
+// references at 24 + k; slack at 28 + k (NaN marks an empty slot: no comparison with it holds, so such a child is never entered
+// whatever the ray's interval - a zero would let a ray with t_min <= 0 into the slot's all-zero box).
 static void fold_to_four(FlatBvh& bvh) {
     const uint32_t n2 = bvh.n_nodes;
     if (n2 == 0) return;
@@ -265,7 +267,7 @@ static void fold_to_four(FlatBvh& bvh) {
             if (k >= wide_n[i]) {  // empty slot
                 c = Child{};
                 c.ref = 0xFFFFFFFFu;
-                c.slack = 0.0f;
+                c.slack = std::numeric_limits<float>::quiet_NaN();
             } else if (!(c.ref & 0x80000000u)) {
                 c.ref = new_of[c.ref];
             }
@@ -342,7 +344,7 @@ static void renumber(FlatBvh& bvh) {
     for (uint32_t i = n; i-- > 0;) {
         uint32_t children = 0, deepest = 0;
         for (int k = 0; k < BVH_WIDTH; ++k) {
-            if (bvh.nodes[NODE_FLOATS * (size_t)i + NODE_SLACK_AT + k] == 0.0f) continue;
+            if (!(bvh.nodes[NODE_FLOATS * (size_t)i + NODE_SLACK_AT + k] > 0.0f)) continue;  // empty slot (NaN)
             ++children;
             uint32_t r = child(i, k);
             if (!(r & 0x80000000u)) deepest = std::max(deepest, need[r]);

@@ -23,7 +23,7 @@ constexpr int BVH_WIDTH = RT_BVH_WIDTH;
 static_assert(BVH_WIDTH == 2 || BVH_WIDTH == 4, "the BVH has 2 or 4 children per node");
 constexpr int NODE_FLOATS = 8 * BVH_WIDTH;          // layout documented in rt_device.h
 constexpr int NODE_REFS_AT = 6 * BVH_WIDTH;         // float index of the first child reference
-constexpr int NODE_SLACK_AT = 7 * BVH_WIDTH;        // float index of the first child's slack factor (an empty slot has slack 0)
+constexpr int NODE_SLACK_AT = 7 * BVH_WIDTH;        // float index of the first child's slack factor (an empty slot has slack NaN)
 
 struct FlatBvh {
     std::vector<float> nodes;  // NODE_FLOATS * n_nodes

@@ -40,8 +40,8 @@ RT_HD bool ref_placed(uint32_t r) { return (r & REF_PLACED) != 0; }
 //             [4]   = min.z, max.z of child 0 | of child 1      [5] = the same for children 2, 3
 //             [6]   = bits(child references)                    [7] = slack of each child
 //           slack multiplies the child's exit distance: 1 for a leaf whose box is the
-//           reference's own AABB (tested exactly), 1 + 2 ulp for conservative boxes, 0 for an
-//           empty slot (never entered).  With RT_BVH_WIDTH=2 a node is 4 x float4:
+//           reference's own AABB (tested exactly), 1 + 2 ulp for conservative boxes, NaN for an
+//           empty slot (never entered: no comparison with NaN holds).  With RT_BVH_WIDTH=2 a node is 4 x float4:
 //             [0] = l.min.xy, l.max.xy   [1] = r.min.xy, r.max.xy
 //             [2] = l.min.z, l.max.z, r.min.z, r.max.z   [3] = bits(left), bits(right), slacks
 //           Nodes are numbered breadth-first for the first levels (the part of the tree every

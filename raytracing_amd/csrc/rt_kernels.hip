@@ -317,6 +317,7 @@ RT_D bool medium_root(const DScene& sc, uint32_t idx, float3 o, float3 d, float 
 static constexpr uint32_t REF_DONE = 0xFFFFFFFEu;  // traversal finished (never a valid reference)
 
 struct PrivateStack {  // per-lane array (scratch memory): used by the record-based entry points
+    static constexpr bool ANY_INTERVAL = true;  // its rays come with the caller's interval: zero, negative, empty
     uint32_t ref[STACK_SIZE];
     float t[STACK_SIZE];
     int sp = 0;
@@ -339,6 +340,7 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(1))) unsigned long long global_u64;
 template <int LEVELS>
 struct WaveStack {
+    static constexpr bool ANY_INTERVAL = false;  // its rays are a render's: t_min = 0.001
     lds_u64* lds;     // this lane's column: level k at lds[64 * k]
     global_u64* ovf;  // level LEVELS + k at ovf[64 * k]
     int sp = 0;
@@ -477,7 +479,9 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
         const float2v z = (float2v{zs[2 * k], zs[2 * k + 1]} - ozz) * izz;
         const float t_in = fmaxf(fmaxf(fminf(lo.x, hi.x), fminf(lo.y, hi.y)), fmaxf(fminf(z.x, z.y), r.tmin));
         const float t_out = fminf(fminf(fmaxf(lo.x, hi.x), fmaxf(lo.y, hi.y)), fminf(fmaxf(z.x, z.y), tmax));
-        key[k] = t_in <= t_out * slack[k] ? __float_as_uint(t_in) : 0xFFFFFFFFu;  // slack 0: empty slot
+        // a negative exit distance (only a caller's interval reaches below zero) is widened towards zero: 2 - slack = 1 - 2 ulp
+        const float wide = Stack::ANY_INTERVAL && t_out < 0.0f ? 2.0f - slack[k] : slack[k];
+        key[k] = t_in <= t_out * wide ? __float_as_uint(t_in) : 0xFFFFFFFFu;  // slack NaN: empty slot, never entered
         ref[k] = refs[k];
     }
     order2(key[0], ref[0], key[1], ref[1]);

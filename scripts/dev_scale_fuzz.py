@@ -112,6 +112,22 @@ for seed in [int(x) for x in os.environ.get("SEEDS", ",".join(str(i) for i in ra
             for i in j[:3]:
                 print("    hit mat", want[keep]["material"][i], "p", want[keep]["point"][i], "uv", want[keep]["u"][i], want[keep]["v"][i], "| dir", sc_c["direction"][i], sc_g["direction"][i],
                       "att", att_c[i], att_g[i], "emit", em_c[i], em_g[i], "tmin", sc_c["tmin"][i], sc_g["tmin"][i])
+    if os.environ.get("INTERVALS"):  # the per-ray entry point takes any interval: zero, negative, empty, short ones
+        odd = rays.copy()
+        scale_t = 10.0 ** rng.uniform(-2, 5, n)
+        odd["tmin"] = rng.choice(np.array([0.0, 0.001, -1.0, 0.5, 10.0], np.float32), n) * rng.choice(np.array([1.0, 0.0]), n, p=[0.7, 0.3]) * scale_t
+        odd["tmax"] = np.where(rng.random(n) < 0.4, np.inf, rng.uniform(-0.5, 3.0, n) * scale_t).astype(np.float32)
+        w2, g2 = cpu.intersect(odd, seed=seed), gpu.intersect(odd, seed=seed)
+        with np.errstate(all="ignore"):
+            rel2 = np.abs(g2["t"] - w2["t"]) / np.maximum(np.abs(w2["t"]), 1e-30)
+        both2 = (w2["hit"] == 1) & (g2["hit"] == 1)
+        far2 = (is_medium(g2) | is_medium(w2)) & (np.maximum(np.where(g2["hit"] == 1, np.abs(g2["t"]), 0), np.where(w2["hit"] == 1, np.abs(w2["t"]), 0)) >= 2048)
+        wrong2 = ((g2["hit"] != w2["hit"]) | (both2 & (g2["prim_id"] != w2["prim_id"]) & (rel2 > 1e-5)) | (both2 & (g2["prim_id"] == w2["prim_id"]) & (rel2 > 1e-4))) & ~far2
+        print(f"  seed {seed}: odd intervals: hit {both2.mean():.2f}, wrong {int(wrong2.sum())}{' FAILED' if wrong2.any() else ''}", flush=True)
+        bad += bool(wrong2.any())
+        for i in np.nonzero(wrong2)[0][:4]:
+            print("    ray", i, "o", odd["origin"][i], "d", odd["direction"][i], "interval", odd["tmin"][i], odd["tmax"][i], "time", odd["time"][i])
+            print("      want hit", w2["hit"][i], "prim", w2["prim_id"][i], "t", w2["t"][i], "n", w2["normal"][i], "| got hit", g2["hit"][i], "prim", g2["prim_id"][i], "t", g2["t"][i], "n", g2["normal"][i])
     if os.environ.get("RENDER"):  # the whole path: a small image with shared random numbers, pixel by pixel
         spp = 4
         gpu.set_seed(seed)

@@ -17,7 +17,7 @@ static void run(const char* name, std::vector<BuildPrim> p, int threads) {
         if (r >= b.n_nodes) { printf("%s: bad node ref %u\n", name, r); return; }
         for (int k = 0; k < BVH_WIDTH; ++k) {
             float slack = b.nodes[(size_t)NODE_FLOATS * r + NODE_SLACK_AT + k];
-            if (slack == 0.0f) continue;
+            if (!(slack > 0.0f)) continue;  // empty slot (NaN)
             uint32_t c; std::memcpy(&c, &b.nodes[(size_t)NODE_FLOATS * r + NODE_REFS_AT + k], 4);
             todo.push_back(c);
         }

@@ -1193,6 +1193,37 @@ def test_box_bounded_media_far_along_a_ray(placed):
     assert (np.abs(a["t"][hit] - want["t"][hit]) <= 2e-5 * np.maximum(1.0, np.abs(want["t"][hit]))).all()
 
 
+def test_intervals_that_start_at_or_below_zero_never_enter_an_empty_child_slot():
+    """A node of four children with fewer than four leaves under it has empty slots (all-zero box, no reference).  The
+    per-ray entry point takes any interval: a ray whose line passes through the world's origin with t_min <= 0 would find
+    that zero box "hit" at t_in <= 0 unless the slot can never compare true.  Five to seven leaves (slots left empty at
+    several places), rays through the origin in both directions, intervals from -inf: hit for hit the restatement's."""
+    for n_leaves in (5, 6, 7, 9):
+        def build(s):
+            t = s.tex_solid(0.5, 0.5, 0.5)
+            lam = s.lambertian(t)
+            items = [s.sphere((3.0 * i - 6.0, 1.0 + i, 2.0 - i), 0.8, lam) for i in range(n_leaves)]
+            s.set_world(s.bvh(items))
+            s.camera((0, 0, -20), 16, 16, max_depth=2, vfov=40.0, background=(0.5, 0.5, 0.5), yaw=90.0)
+            return s
+        gpu, cpu = build(rt.Scene()), build(ob.OracleScene())
+        rng = np.random.default_rng(n_leaves)
+        n = 4000
+        rays = np.zeros(n, _abi.ray_dtype())
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        rays["direction"] = d
+        rays["origin"] = (d.astype(np.float64) * rng.uniform(-8, 8, (n, 1))).astype(np.float32)    # on a line through (0, 0, 0)
+        rays["origin"][::4] = rng.uniform(-8, 8, (len(rays[::4]), 3))                               # and some anywhere
+        rays["tmin"] = rng.choice(np.array([0.0, -0.0, -1.0, -100.0, -np.inf, 0.001], np.float32), n)
+        rays["tmax"] = rng.choice(np.array([np.inf, 0.0, 5.0, -0.5, 100.0], np.float32), n)
+        rays["rng_pixel"], rays["rng_sample"] = np.arange(n) % 256, 1 + np.arange(n) // 256
+        want, got = cpu.intersect(rays), gpu.intersect(rays)
+        assert np.array_equal(got["hit"], want["hit"]), n_leaves
+        hit = want["hit"] == 1
+        assert hit.mean() > 0.02
+        assert np.array_equal(got["prim_id"][hit], want["prim_id"][hit]) and np.array_equal(got["t"][hit], want["t"][hit]), n_leaves
+
+
 def test_extend_kernel_rejects_rays_the_render_path_never_casts():
     s = rt.Scene.builtin(6, 16, 16)
     rays = s.primary_rays(np.arange(4, dtype=np.uint32), 1)
