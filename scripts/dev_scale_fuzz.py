@@ -86,7 +86,17 @@ for seed in [int(x) for x in os.environ.get("SEEDS", ",".join(str(i) for i in ra
     far_medium = (is_medium(a) | is_medium(want)) & far
     wrong_flag = (a["hit"] != want["hit"]) & ~far_medium
     wrong_prim = hit & ~same_prim & ~tie & ~far_medium
-    wrong_t = same_prim & (rel > 1e-4)
+    # t on the same leaf: within 1e-4, or - for hits a hair from the origin, where t is a difference of large numbers - the
+    # hit point within 1e-5 of the size of the coordinates involved
+    dlen = np.linalg.norm(rays["direction"], axis=1)
+    coords = np.maximum(np.abs(rays["origin"]).max(axis=1), np.abs(want["t"]) * dlen)
+    with np.errstate(all="ignore"):
+        wrong_t = same_prim & (rel > 1e-4) & (np.abs(a["t"] - want["t"]) * dlen > 1e-5 * coords)
+    # a grazing hit (normal at right angles to the ray to 1e-2) on one side only: an ulp of the origin decides it (Move drift)
+    def grazing(h):
+        with np.errstate(all="ignore"):
+            return (h["hit"] == 1) & (np.abs((h["normal"] * rays["direction"]).sum(axis=1)) <= 1e-2 * dlen)
+    wrong_flag &= ~(grazing(a) | grazing(want))
     n_flag, n_prim, n_t = int(wrong_flag.sum()), int(wrong_prim.sum()), int(wrong_t.sum())
     n_far, n_loose = int((far_medium & ((a["hit"] != want["hit"]) | (hit & ~same_prim & ~tie))).sum()), int((same_prim & (rel > 2e-5) & ~wrong_t).sum())
     good = same_ab and n_flag == 0 and n_prim == 0 and n_t == 0
@@ -122,7 +132,13 @@ for seed in [int(x) for x in os.environ.get("SEEDS", ",".join(str(i) for i in ra
             rel2 = np.abs(g2["t"] - w2["t"]) / np.maximum(np.abs(w2["t"]), 1e-30)
         both2 = (w2["hit"] == 1) & (g2["hit"] == 1)
         far2 = (is_medium(g2) | is_medium(w2)) & (np.maximum(np.where(g2["hit"] == 1, np.abs(g2["t"]), 0), np.where(w2["hit"] == 1, np.abs(w2["t"]), 0)) >= 2048)
-        wrong2 = ((g2["hit"] != w2["hit"]) | (both2 & (g2["prim_id"] != w2["prim_id"]) & (rel2 > 1e-5)) | (both2 & (g2["prim_id"] == w2["prim_id"]) & (rel2 > 1e-4))) & ~far2
+        coords2 = np.maximum(np.abs(odd["origin"]).max(axis=1), np.abs(w2["t"]) * dlen)
+        def grazing2(h):
+            with np.errstate(all="ignore"):
+                return (h["hit"] == 1) & (np.abs((h["normal"] * odd["direction"]).sum(axis=1)) <= 1e-2 * dlen)
+        with np.errstate(all="ignore"):
+            t_off = both2 & (g2["prim_id"] == w2["prim_id"]) & (rel2 > 1e-4) & (np.abs(g2["t"] - w2["t"]) * dlen > 1e-5 * coords2)
+        wrong2 = (((g2["hit"] != w2["hit"]) & ~(grazing2(g2) | grazing2(w2))) | (both2 & (g2["prim_id"] != w2["prim_id"]) & (rel2 > 1e-5)) | t_off) & ~far2
         print(f"  seed {seed}: odd intervals: hit {both2.mean():.2f}, wrong {int(wrong2.sum())}{' FAILED' if wrong2.any() else ''}", flush=True)
         bad += bool(wrong2.any())
         for i in np.nonzero(wrong2)[0][:4]:
