@@ -1003,6 +1003,19 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
 
     std::vector<float4> nodes(bvh.nodes.size() / 4);
     if (!nodes.empty()) std::memcpy(nodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
+#if RT_BVH_WIDTH == 4
+    // the kernels' layout of a node (rt_device.h): bounds by axis and side, four children each, from the builder's by child
+    for (uint32_t i = 0; i < bvh.n_nodes; ++i) {
+        const float* q = &bvh.nodes[rt::NODE_FLOATS * (size_t)i];
+        float4* n = &nodes[8 * (size_t)i];
+        n[0] = make_float4(q[0], q[4], q[8], q[12]);    // min.x
+        n[1] = make_float4(q[2], q[6], q[10], q[14]);   // max.x
+        n[2] = make_float4(q[1], q[5], q[9], q[13]);    // min.y
+        n[3] = make_float4(q[3], q[7], q[11], q[15]);   // max.y
+        n[4] = make_float4(q[16], q[18], q[20], q[22]); // min.z
+        n[5] = make_float4(q[17], q[19], q[21], q[23]); // max.z
+    }
+#endif
     if ((e = upload(sc, nodes, &sc->d.nodes))) return bail(e);
     if ((e = upload(sc, spheres, &sc->d.spheres))) return bail(e);
     if ((e = upload(sc, sphere_meta, &sc->d.sphere_meta))) return bail(e);

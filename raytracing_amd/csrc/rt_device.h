@@ -35,10 +35,11 @@ RT_HD bool ref_placed(uint32_t r) { return (r & REF_PLACED) != 0; }
 
 // ---------------------------------------------------------------------------
 // HBM layout (all arrays 16-byte aligned, one or more float4 per element):
-//   nodes   8 x float4 per node of four children (128 B), laid out for two-wide (packed) arithmetic:
-//             [k]   = child k: min.xy, max.xy                      (k = 0..3)
-//             [4]   = min.z, max.z of child 0 | of child 1      [5] = the same for children 2, 3
+//   nodes   8 x float4 per node of four children (128 B), bounds by axis and side so that a ray reads the side it
+//           meets first / last of all four children with one 16-byte load each, picked by the sign of its direction:
+//             [0] = min.x of children 0..3   [1] = max.x   [2] = min.y   [3] = max.y   [4] = min.z   [5] = max.z
 //             [6]   = bits(child references)                    [7] = slack of each child
+//           (the builder's own array, rt_bvh.h, is by child; rt_scene_create transposes it)
 //           slack multiplies the child's exit distance: 1 for a leaf whose box is the
 //           reference's own AABB (tested exactly), 1 + 2 ulp for conservative boxes, NaN for an
 //           empty slot (never entered: no comparison with NaN holds).  With RT_BVH_WIDTH=2 a node is 4 x float4:

@@ -342,12 +342,13 @@ template <int LEVELS>
 struct WaveStack {
     static constexpr bool ANY_INTERVAL = false;  // its rays are a render's: t_min = 0.001
     lds_u64* lds;     // this lane's column: level k at lds[64 * k]
-    global_u64* ovf;  // level LEVELS + k at ovf[64 * k]
+    global_u64* ovf;  // the wave's area (the same pointer in all its lanes, so it lives in scalar registers): level LEVELS + k of lane l at ovf[64 * k + l]
+    uint32_t lane;
     int sp = 0;
     RT_D void push(uint32_t r, float tt) {
         unsigned long long e = ((unsigned long long)__float_as_uint(tt) << 32) | r;
         if (sp < LEVELS) lds[64 * sp] = e;
-        else ovf[64 * (sp - LEVELS)] = e;
+        else ovf[64u * (uint32_t)(sp - LEVELS) + lane] = e;
         ++sp;
     }
     RT_D bool pop(uint32_t& r, float& tt) {
@@ -355,7 +356,7 @@ struct WaveStack {
         --sp;
         unsigned long long e;
         if (sp < LEVELS) e = lds[64 * sp];
-        else e = ovf[64 * (sp - LEVELS)];
+        else e = ovf[64u * (uint32_t)(sp - LEVELS) + lane];
         r = (uint32_t)e;
         tt = __uint_as_float((uint32_t)(e >> 32));
         return true;
@@ -365,6 +366,7 @@ struct WaveStack {
 struct TravRay {
     float3 o, d, inv;
     float time, a, tmin;
+    bool odd;  // some component of the origin or of 1 / direction is not finite, or 1 / direction is zero: see node_step
 };
 
 RT_D TravRay make_trav_ray(float3 o, float3 d, float time, float tmin) {
@@ -372,6 +374,8 @@ RT_D TravRay make_trav_ray(float3 o, float3 d, float time, float tmin) {
     r.o = o; r.d = d; r.time = time; r.tmin = tmin;
     r.a = dot3(d, d);
     r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    auto plain = [](float inv, float o) { return fabsf(inv) > 0.0f && fabsf(inv) < RT_INF && fabsf(o) < RT_INF; };
+    r.odd = !(plain(r.inv.x, o.x) && plain(r.inv.y, o.y) && plain(r.inv.z, o.z));
     return r;
 }
 
@@ -410,7 +414,7 @@ static constexpr uint32_t NODE_FLOAT4S = NODE_FLOATS / 4;
 // slack 1, so the same leaves get tested as in the reference.
 #if RT_BVH_WIDTH == 2
 template <bool COUNT, bool LDS_TOP, class Stack>
-RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr) {
+RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr, bool /*odd*/) {
     if (COUNT) pr.nodes++;
     float4 n0, n1, n2, n3;
     if (LDS_TOP && cur < src.n_top) {
@@ -445,8 +449,15 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
     return pop_next(st, tmax);
 }
 #else
-// Four children per node.  Each child's slab test is the two-child one above; the children that
-// are hit are ordered by entry distance with a five-exchange sorting network (entry distances
+// Four children per node.  Each child's slab test is the two-child one above, with one shortcut: a node stores its
+// children's bounds one axis and one side at a time (min.x of the four children, max.x, min.y, ...), so a ray reads,
+// per axis, the bounds it meets first and the bounds it meets last straight from the side its direction's sign names.
+// For min <= max and a finite non-zero 1 / direction, (near - o) * inv <= (far - o) * inv holds in floating point as
+// it does in the reals (subtraction and multiplication round monotonically), so the pair is exactly the
+// (min(t0, t1), max(t0, t1)) of AABBx2::hit (src/math/aabb.rs:127-167) with no min / max spent on it.  Rays for which
+// that does not hold (a zero, infinite or NaN direction component: t0 or t1 can be NaN, and which one the reference's
+// NaN-dropping min / max keep depends on both) take the min / max as well: `odd`, the same for every lane of the wave.
+// The children that are hit are ordered by entry distance with a five-exchange sorting network (entry distances
 // are positive, so their bit patterns order like the numbers; a child that is missed gets the
 // key ~0), the nearest is continued with and the others are stacked farthest first.
 RT_D void order2(uint32_t& ka, uint32_t& ra, uint32_t& kb, uint32_t& rb) {
@@ -454,34 +465,100 @@ RT_D void order2(uint32_t& ka, uint32_t& ra, uint32_t& kb, uint32_t& rb) {
     const uint32_t k0 = swap ? kb : ka, k1 = swap ? ka : kb, r0 = swap ? rb : ra, r1 = swap ? ra : rb;
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
+typedef __attribute__((address_space(3))) const char lds_bytes;
+// (a - b[SEL]) * c[SEL2] for both halves of a, each operation rounded once: packed subtract and multiply that take one
+// half of their second operand for both lanes (operand selection is part of the instruction; the compiler would copy
+// the half into a register pair of its own instead, and the extend kernel has no registers to spare).
+template <int SEL>
+RT_D float2v pk_sub_half(float2v a, float2v b) {
+    float2v d;
+    if (SEL == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <int SEL>
+RT_D float2v pk_mul_half(float2v a, float2v b) {
+    float2v d;
+    if (SEL == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 template <bool COUNT, bool LDS_TOP, class Stack>
-RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr) {
+RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr, bool odd) {
     if (COUNT) pr.nodes++;
-    float4 q[8];
+    // byte offsets inside the node array: 32 bytes per axis, the side met first picked by the sign of 1 / direction
+    const uint32_t base = cur * (uint32_t)(NODE_FLOATS * sizeof(float));
+    // (the sign bits are taken anew at every node - volatile keeps the compiler from holding three registers for them
+    // through the whole kernel, which has none to spare)
+    uint32_t sx, sy, sz;
+    asm volatile("v_bfe_u32 %0, %1, 31, 1" : "=v"(sx) : "v"(r.inv.x));
+    asm volatile("v_bfe_u32 %0, %1, 31, 1" : "=v"(sy) : "v"(r.inv.y));
+    asm volatile("v_bfe_u32 %0, %1, 31, 1" : "=v"(sz) : "v"(r.inv.z));
+    const uint32_t ax = base | (sx << 4), ay = (base + 32u) | (sy << 4), az = (base + 64u) | (sz << 4);
+    float4 nx, fx, ny, fy, nz, fz, q6, q7;
     if (LDS_TOP && cur < src.n_top) {
-        const lds_float4v* n = (const lds_float4v*)src.top + 8 * cur;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = f4(n[i]);
+        lds_bytes* n = (lds_bytes*)src.top;
+        nx = f4(*(const lds_float4v*)(n + ax)); fx = f4(*(const lds_float4v*)(n + (ax ^ 16u)));
+        ny = f4(*(const lds_float4v*)(n + ay)); fy = f4(*(const lds_float4v*)(n + (ay ^ 16u)));
+        nz = f4(*(const lds_float4v*)(n + az)); fz = f4(*(const lds_float4v*)(n + (az ^ 16u)));
+        q6 = f4(*(const lds_float4v*)(n + (base + 96u))); q7 = f4(*(const lds_float4v*)(n + (base + 112u)));
     } else {
-        const float4* n = src.nodes + 8 * (size_t)cur;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = n[i];
+        const char* n = (const char*)src.nodes;
+        nx = *(const float4*)(n + ax); fx = *(const float4*)(n + (ax ^ 16u));
+        ny = *(const float4*)(n + ay); fy = *(const float4*)(n + (ay ^ 16u));
+        nz = *(const float4*)(n + az); fz = *(const float4*)(n + (az ^ 16u));
+        q6 = *(const float4*)(n + (base + 96u)); q7 = *(const float4*)(n + (base + 112u));
     }
-    const float2v oxy = {r.o.x, r.o.y}, ixy = {r.inv.x, r.inv.y}, ozz = {r.o.z, r.o.z}, izz = {r.inv.z, r.inv.z};
-    const float zs[8] = {q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w};
-    const uint32_t refs[4] = {__float_as_uint(q[6].x), __float_as_uint(q[6].y), __float_as_uint(q[6].z), __float_as_uint(q[6].w)};
-    const float slack[4] = {q[7].x, q[7].y, q[7].z, q[7].w};
+    const float2v oxy = {r.o.x, r.o.y}, ixy = {r.inv.x, r.inv.y}, zz = {r.o.z, r.inv.z};
+    // entry (tn) and exit (tf) distance of child k along each axis
+    float tn[3][4], tf[3][4];
+    {
+        const float2v a0 = pk_mul_half<0>(pk_sub_half<0>(float2v{nx.x, nx.y}, oxy), ixy), a1 = pk_mul_half<0>(pk_sub_half<0>(float2v{nx.z, nx.w}, oxy), ixy);
+        const float2v b0 = pk_mul_half<0>(pk_sub_half<0>(float2v{fx.x, fx.y}, oxy), ixy), b1 = pk_mul_half<0>(pk_sub_half<0>(float2v{fx.z, fx.w}, oxy), ixy);
+        tn[0][0] = a0.x; tn[0][1] = a0.y; tn[0][2] = a1.x; tn[0][3] = a1.y;
+        tf[0][0] = b0.x; tf[0][1] = b0.y; tf[0][2] = b1.x; tf[0][3] = b1.y;
+    }
+    {
+        const float2v a0 = pk_mul_half<1>(pk_sub_half<1>(float2v{ny.x, ny.y}, oxy), ixy), a1 = pk_mul_half<1>(pk_sub_half<1>(float2v{ny.z, ny.w}, oxy), ixy);
+        const float2v b0 = pk_mul_half<1>(pk_sub_half<1>(float2v{fy.x, fy.y}, oxy), ixy), b1 = pk_mul_half<1>(pk_sub_half<1>(float2v{fy.z, fy.w}, oxy), ixy);
+        tn[1][0] = a0.x; tn[1][1] = a0.y; tn[1][2] = a1.x; tn[1][3] = a1.y;
+        tf[1][0] = b0.x; tf[1][1] = b0.y; tf[1][2] = b1.x; tf[1][3] = b1.y;
+    }
+    {
+        const float2v a0 = pk_mul_half<1>(pk_sub_half<0>(float2v{nz.x, nz.y}, zz), zz), a1 = pk_mul_half<1>(pk_sub_half<0>(float2v{nz.z, nz.w}, zz), zz);
+        const float2v b0 = pk_mul_half<1>(pk_sub_half<0>(float2v{fz.x, fz.y}, zz), zz), b1 = pk_mul_half<1>(pk_sub_half<0>(float2v{fz.z, fz.w}, zz), zz);
+        tn[2][0] = a0.x; tn[2][1] = a0.y; tn[2][2] = a1.x; tn[2][3] = a1.y;
+        tf[2][0] = b0.x; tf[2][1] = b0.y; tf[2][2] = b1.x; tf[2][3] = b1.y;
+    }
+    if (odd) {  // NaNs (0 * inf) drop out of fminf/fmaxf, as they do out of simd_min/simd_max in the reference
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = fminf(tn[a][k], tf[a][k]), hi = fmaxf(tn[a][k], tf[a][k]);
+                tn[a][k] = lo;
+                tf[a][k] = hi;
+            }
+    }
+    // max / min over the axes and the ray's interval, NaNs dropping out as above: the instructions fmaxf / fminf compile to,
+    // spelled out so that none is spent on quieting operands that are results of arithmetic
+    float t_in[4], t_out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float a, b;
+        asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(tn[2][k]), "v"(r.tmin));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t_in[k]) : "v"(tn[0][k]), "v"(tn[1][k]), "v"(a));
+        asm("v_min_f32 %0, %1, %2" : "=v"(b) : "v"(tf[2][k]), "v"(tmax));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t_out[k]) : "v"(tf[0][k]), "v"(tf[1][k]), "v"(b));
+    }
+    const uint32_t refs[4] = {__float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w)};
+    const float slack[4] = {q7.x, q7.y, q7.z, q7.w};
     uint32_t key[4], ref[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        // NaNs (0 * inf) drop out of fminf/fmaxf, as they do out of simd_min/simd_max in the reference
-        const float2v lo = (float2v{q[k].x, q[k].y} - oxy) * ixy, hi = (float2v{q[k].z, q[k].w} - oxy) * ixy;
-        const float2v z = (float2v{zs[2 * k], zs[2 * k + 1]} - ozz) * izz;
-        const float t_in = fmaxf(fmaxf(fminf(lo.x, hi.x), fminf(lo.y, hi.y)), fmaxf(fminf(z.x, z.y), r.tmin));
-        const float t_out = fminf(fminf(fmaxf(lo.x, hi.x), fmaxf(lo.y, hi.y)), fminf(fmaxf(z.x, z.y), tmax));
         // a negative exit distance (only a caller's interval reaches below zero) is widened towards zero: 2 - slack = 1 - 2 ulp
-        const float wide = Stack::ANY_INTERVAL && t_out < 0.0f ? 2.0f - slack[k] : slack[k];
-        key[k] = t_in <= t_out * wide ? __float_as_uint(t_in) : 0xFFFFFFFFu;  // slack NaN: empty slot, never entered
+        const float wide = Stack::ANY_INTERVAL && t_out[k] < 0.0f ? 2.0f - slack[k] : slack[k];
+        key[k] = t_in[k] <= t_out[k] * wide ? __float_as_uint(t_in[k]) : 0xFFFFFFFFu;  // slack NaN: empty slot, never entered
         ref[k] = refs[k];
     }
     order2(key[0], ref[0], key[1], ref[1]);
@@ -610,8 +687,9 @@ template <bool COUNT, bool GENERIC, class Stack, class Key>
 RT_D void walk_tree(const DScene& sc, const TravRay& r, float& tmax, uint32_t& best, const Key& key, Stack& st, Probe& pr) {
     const NodeSource src{sc.nodes, nullptr, 0};
     uint32_t cur = sc.root == REF_NONE ? REF_DONE : sc.root;
+    const bool odd = __ballot(r.odd) != 0;  // the same for the whole wave
     while (cur != REF_DONE) {
-        if (!ref_is_leaf(cur)) cur = node_step<COUNT, false>(src, r, cur, tmax, st, pr);
+        if (!ref_is_leaf(cur)) cur = node_step<COUNT, false>(src, r, cur, tmax, st, pr, odd);
         else cur = leaf_step<COUNT, GENERIC>(sc, r, cur, tmax, best, key, st, pr);
     }
 }
@@ -1156,7 +1234,8 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
 
     WaveStack<LDS_STACK> st;
     st.lds = (lds_u64*)&s_stack[wave_in_block][0][lane];
-    st.ovf = (global_u64*)(stack_overflow + ((size_t)wave * OVERFLOW_STACK) * 64 + lane);
+    st.ovf = (global_u64*)(stack_overflow + ((size_t)wave * OVERFLOW_STACK) * 64);
+    st.lane = lane;
     Probe pr;
     uint32_t segs = 0, nhit = 0, slots = 0;
 
@@ -1167,6 +1246,8 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
     BatchMediumKey key{seed, 0, bounce, b};
     const uint32_t root = sc.root == REF_NONE ? REF_DONE : sc.root;
     const bool first_leaves_done = sc.n_global != 0;  // k_first_leaves has run: hits[] holds each ray's starting (tmax, leaf)
+
+    bool odd = false;  // some ray this wave has fetched needs node_step's min / max; stays on to the end of the launch
 
     // A turn in which no part ran (the thresholds below held every lane back) is followed by one
     // that runs every part for whatever lanes it has, so the loop always moves on.
@@ -1201,7 +1282,9 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             if (COUNT) slots++;
 #endif
             uint32_t rank = (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull));
-            if (mine == REF_NONE && rank < avail) {
+            const bool fetch = mine == REF_NONE && rank < avail;
+            bool odd_ray = false;
+            if (fetch) {
                 mine = next + rank;
                 float4 ro = ray_o[mine], rd = ray_d[mine];
                 key.path = __float_as_uint(rd.w);
@@ -1215,7 +1298,9 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
                 }
                 st.sp = 0;
                 cur = root;
+                odd_ray = r.odd;
             }
+            if (__ballot(odd_ray) != 0) odd = true;
             next += n_refill;
         }
         // inner nodes
@@ -1235,7 +1320,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             if (COUNT) slots++;
 #endif
             if (at_inner) {
-                cur = node_step<COUNT, SMALL_TREE>(src, r, cur, tmax, st, pr);
+                cur = node_step<COUNT, SMALL_TREE>(src, r, cur, tmax, st, pr, odd);
                 if (COUNT) pr.max_sp = max(pr.max_sp, (uint32_t)st.sp);
             }
         }
@@ -1575,7 +1660,8 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(DScene sc, DCamera cam, Bat
     if (wave >= n) return;
     WaveStack<RT_EXTEND_STACK> st;
     st.lds = (lds_u64*)&s_stack[wave_in_block][0][lane];
-    st.ovf = (global_u64*)(stack_overflow + ((size_t)wave * OVERFLOW_STACK) * 64 + lane);
+    st.ovf = (global_u64*)(stack_overflow + ((size_t)wave * OVERFLOW_STACK) * 64);
+    st.lane = lane;
     Probe pr;
     unsigned long long next = (unsigned long long)wave + (unsigned long long)lane * n_waves;  // this lane's next ray
     const unsigned long long step = 64ull * n_waves;
