@@ -1282,6 +1282,7 @@ static int render_rows(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, u
     // persistent grid of the extend kernel; a preallocated overflow area bounds it for the trees that use that area
     uint32_t extend_grid = extend_grid_of(c, sc, c->counters_on);
     if (fixed && needs_overflow(sc)) extend_grid = std::min(extend_grid, NOALLOC_OVERFLOW_BLOCKS);
+    const bool overflow_needed = needs_overflow(sc);  // else the extend kernel runs the variant without the global part of its stack
     DCamera dcam = to_dcamera(cam);
     DCounters* counters = c->counters_on ? c->d_counters : nullptr;
     rt::ExtendTuning tune = c->tune;
@@ -1322,7 +1323,7 @@ static int render_rows(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, u
                     }
                     if ((e = phase_begin(c, timing, st, 1, &ep))) return e;
                     launch_extend(st, extend_grid, total, sc->d, b, seed, bounce, q.counts, q.ray_o[cur],
-                                  q.ray_d[cur], q.hits, q.stack_overflow, tune, counters);
+                                  q.ray_d[cur], q.hits, overflow_needed ? q.stack_overflow : nullptr, tune, counters);
                     if ((e = phase_end(st, ep))) return e;
                     if ((e = phase_begin(c, timing, st, 2, &ep))) return e;
                     launch_shade(st, c->max_blocks, total, sc->d, dcam, b, seed, bounce, q.counts, q.counts + n_queue_counts + bounce, q.tex_list,
@@ -1693,7 +1694,7 @@ int rt_extend_batch(rt_scene* sc, const rt_ray* rays, size_t n, uint64_t seed, r
                 launch_first_leaves(st, c->max_blocks, group_size[bounce], sc->d, b, seed, bounce, q.counts, q.ray_o[0] + at, q.ray_d[0] + at,
                                     q.hits + at, counters);
             launch_extend(st, extend_grid_of(c, sc, counters != nullptr), group_size[bounce], sc->d, b, seed, bounce, q.counts,
-                          q.ray_o[0] + at, q.ray_d[0] + at, q.hits + at, q.stack_overflow, tune, counters);
+                          q.ray_o[0] + at, q.ray_d[0] + at, q.hits + at, needs_overflow(sc) ? q.stack_overflow : nullptr, tune, counters);
         }
         launch_unpack_hits(st, c->max_blocks, sc->d, d_rays, q.hits, n, d_hits);
         he = hipGetLastError();

@@ -338,7 +338,8 @@ struct PrivateStack {  // per-lane array (scratch memory): used by the record-ba
 // spelled out so that every access compiles to a plain ds_ or global_ instruction.
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(1))) unsigned long long global_u64;
-template <int LEVELS>
+// OVERFLOW false: for trees whose walks never stack more than LEVELS entries (the builder's bound), no global part.
+template <int LEVELS, bool OVERFLOW = true>
 struct WaveStack {
     static constexpr bool ANY_INTERVAL = false;  // its rays are a render's: t_min = 0.001
     lds_u64* lds;     // this lane's column: level k at lds[64 * k]
@@ -347,7 +348,7 @@ struct WaveStack {
     int sp = 0;
     RT_D void push(uint32_t r, float tt) {
         unsigned long long e = ((unsigned long long)__float_as_uint(tt) << 32) | r;
-        if (sp < LEVELS) lds[64 * sp] = e;
+        if (!OVERFLOW || sp < LEVELS) lds[64 * sp] = e;
         else ovf[64u * (uint32_t)(sp - LEVELS) + lane] = e;
         ++sp;
     }
@@ -355,7 +356,7 @@ struct WaveStack {
         if (sp == 0) return false;
         --sp;
         unsigned long long e;
-        if (sp < LEVELS) e = lds[64 * sp];
+        if (!OVERFLOW || sp < LEVELS) e = lds[64 * sp];
         else e = ovf[64u * (uint32_t)(sp - LEVELS) + lane];
         r = (uint32_t)e;
         tt = __uint_as_float((uint32_t)(e >> 32));
@@ -363,6 +364,10 @@ struct WaveStack {
     }
 };
 
+// Start of the interval of every ray of a render (src/camera.rs:346: Interval::new(0.001, f32::MAX)); rays that come with
+// the caller's own interval go through PrivateStack (ANY_INTERVAL).
+static constexpr float RENDER_TMIN = 0.001f;
+static_assert(__builtin_bit_cast(uint32_t, RENDER_TMIN) == 0x3a83126fu, "node_step spells this constant out in an instruction");
 struct TravRay {
     float3 o, d, inv;
     float time, a, tmin;
@@ -542,23 +547,34 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
     }
     // max / min over the axes and the ray's interval, NaNs dropping out as above: the instructions fmaxf / fminf compile to,
     // spelled out so that none is spent on quieting operands that are results of arithmetic
-    float t_in[4], t_out[4];
+    float t_in[4];
+    float2v t_out[2];  // children 0, 1 | 2, 3: pairs, so that the slack factors multiply them two at a time
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float a, b;
-        asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(tn[2][k]), "v"(r.tmin));
+        float a, b, c;
+        if (Stack::ANY_INTERVAL) asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(tn[2][k]), "v"(r.tmin));
+        else asm("v_max_f32 %0, 0x3a83126f, %1" : "=v"(a) : "v"(tn[2][k]));  // RENDER_TMIN as a literal: no register holds it
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t_in[k]) : "v"(tn[0][k]), "v"(tn[1][k]), "v"(a));
         asm("v_min_f32 %0, %1, %2" : "=v"(b) : "v"(tf[2][k]), "v"(tmax));
-        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t_out[k]) : "v"(tf[0][k]), "v"(tf[1][k]), "v"(b));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(c) : "v"(tf[0][k]), "v"(tf[1][k]), "v"(b));
+        if (k & 1) t_out[k / 2].y = c;
+        else t_out[k / 2].x = c;
     }
     const uint32_t refs[4] = {__float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w)};
-    const float slack[4] = {q7.x, q7.y, q7.z, q7.w};
+    float2v slack[2] = {{q7.x, q7.y}, {q7.z, q7.w}};
+    if (Stack::ANY_INTERVAL) {
+        // a negative exit distance (only a caller's interval reaches below zero) is widened towards zero: 2 - slack = 1 - 2 ulp
+        if (t_out[0].x < 0.0f) slack[0].x = 2.0f - slack[0].x;
+        if (t_out[0].y < 0.0f) slack[0].y = 2.0f - slack[0].y;
+        if (t_out[1].x < 0.0f) slack[1].x = 2.0f - slack[1].x;
+        if (t_out[1].y < 0.0f) slack[1].y = 2.0f - slack[1].y;
+    }
+    const float2v wide01 = t_out[0] * slack[0], wide23 = t_out[1] * slack[1];
+    const float t_wide[4] = {wide01.x, wide01.y, wide23.x, wide23.y};
     uint32_t key[4], ref[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        // a negative exit distance (only a caller's interval reaches below zero) is widened towards zero: 2 - slack = 1 - 2 ulp
-        const float wide = Stack::ANY_INTERVAL && t_out[k] < 0.0f ? 2.0f - slack[k] : slack[k];
-        key[k] = t_in[k] <= t_out[k] * wide ? __float_as_uint(t_in[k]) : 0xFFFFFFFFu;  // slack NaN: empty slot, never entered
+        key[k] = t_in[k] <= t_wide[k] ? __float_as_uint(t_in[k]) : 0xFFFFFFFFu;  // slack NaN: empty slot, never entered
         ref[k] = refs[k];
     }
     order2(key[0], ref[0], key[1], ref[1]);
@@ -670,7 +686,7 @@ RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_
 template <bool GENERIC>
 RT_D uint2 first_leaves_hit(const DScene& sc, const BatchInfo& b, uint64_t seed, uint32_t bounce, float4 ro, float4 rd) {
     BatchMediumKey key{seed, __float_as_uint(rd.w), bounce, b};
-    TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
+    TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, RENDER_TMIN);
     float tmax = RT_INF;
     uint32_t best = REF_NONE;
     Probe pr;
@@ -1204,7 +1220,7 @@ static constexpr int OVERFLOW_STACK = STACK_SIZE - MIN_LDS_STACK;
 #ifndef RT_EXTEND_WAVES
 #define RT_EXTEND_WAVES 6  // resident waves per SIMD the register allocation aims for
 #endif
-template <bool COUNT, bool SMALL_TREE, bool GENERIC>
+template <bool COUNT, bool SMALL_TREE, bool GENERIC, bool OVERFLOW = true>
 __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GENERIC ? RT_EXTEND_WAVES - 1 : RT_EXTEND_WAVES, GENERIC ? RT_EXTEND_WAVES - 1 : RT_EXTEND_WAVES))) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                          const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
                                                          const float4* __restrict__ ray_d, uint2* __restrict__ hits,
@@ -1232,7 +1248,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
     uint32_t next = blk * 64u;
     uint32_t blk_end = min(n, next + 64u);
 
-    WaveStack<LDS_STACK> st;
+    WaveStack<LDS_STACK, OVERFLOW> st;
     st.lds = (lds_u64*)&s_stack[wave_in_block][0][lane];
     st.ovf = (global_u64*)(stack_overflow + ((size_t)wave * OVERFLOW_STACK) * 64);
     st.lane = lane;
@@ -1288,7 +1304,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
                 mine = next + rank;
                 float4 ro = ray_o[mine], rd = ray_d[mine];
                 key.path = __float_as_uint(rd.w);
-                r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
+                r = make_trav_ray(f3(ro), f3(rd), ro.w, RENDER_TMIN);
                 tmax = RT_INF;
                 best = REF_NONE;
                 if (first_leaves_done) {
@@ -1377,7 +1393,7 @@ __global__ __launch_bounds__(256) void k_first_leaves(DScene sc, BatchInfo b, ui
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 ro = ray_o[i], rd = ray_d[i];
         BatchMediumKey key{seed, __float_as_uint(rd.w), bounce, b};
-        TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
+        TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, RENDER_TMIN);
         float tmax = RT_INF;
         uint32_t best = REF_NONE;
         global_leaves<COUNT, GENERIC>(sc, r, tmax, best, key, pr);
@@ -1679,7 +1695,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(DScene sc, DCamera cam, Bat
         if (__ballot(have) == 0ull) break;  // no lane has a ray and none could fetch one
         if (have) {
             const BatchMediumKey key{seed, __float_as_uint(rd.w), bounce, b};
-            const TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, 0.001f);
+            const TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, RENDER_TMIN);
             float tmax = RT_INF;
             uint32_t best = REF_NONE;
             global_leaves<false, GENERIC>(sc, r, tmax, best, key, pr);
@@ -1925,9 +1941,13 @@ void launch_extend(hipStream_t st, uint32_t resident_blocks, uint32_t upper_boun
                    unsigned long long* stack_overflow, const ExtendTuning& tune, DCounters* counters) {
     dim3 grid(grid_for(upper_bound, resident_blocks));
     const bool small_tree = sc.n_nodes <= (uint32_t)SMALL_TREE_NODES;
+    // stack_overflow == nullptr: the caller's word that no walk of this tree stacks more entries than the kernel keeps in LDS
     auto kernel = sc.generic_media
         ? (counters ? (small_tree ? k_extend<true, true, true> : k_extend<true, false, true>) : (small_tree ? k_extend<false, true, true> : k_extend<false, false, true>))
         : (counters ? (small_tree ? k_extend<true, true, false> : k_extend<true, false, false>) : (small_tree ? k_extend<false, true, false> : k_extend<false, false, false>));
+    if (!counters && stack_overflow == nullptr)
+        kernel = sc.generic_media ? (small_tree ? k_extend<false, true, true, false> : k_extend<false, false, true, false>)
+                                  : (small_tree ? k_extend<false, true, false, false> : k_extend<false, false, false, false>);
     hipLaunchKernelGGL(kernel, grid, dim3(EXTEND_BLOCK), 0, st, sc, b, seed, bounce, counts, ray_o, ray_d, hits, stack_overflow, tune, counters);
 }
 
