@@ -1079,7 +1079,7 @@ RT_D ScatterResult shade_hit(const DScene& sc, const ShadeRec& m, HitGeom& g, fl
 // counters
 // ---------------------------------------------------------------------------
 #ifndef RT_LANE_STATS
-#define RT_LANE_STATS 0  // development builds: 1..6 count the lane slots of one loop part of k_extend in DCounters::max_stack
+#define RT_LANE_STATS 0  // development builds: 1..8 count the lane slots of one loop part of k_extend in DCounters::max_stack
 #endif
 RT_D unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
@@ -1338,7 +1338,13 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             if (at_inner) {
                 cur = node_step<COUNT, SMALL_TREE>(src, r, cur, tmax, st, pr, odd);
                 if (COUNT) pr.max_sp = max(pr.max_sp, (uint32_t)st.sp);
+#if RT_LANE_STATS == 7
+                if (COUNT && st.sp > LDS_STACK) slots++;  // node steps that leave the lane's stack in the global part
+#endif
             }
+#if RT_LANE_STATS == 8
+            if (COUNT && __ballot(at_inner && st.sp > LDS_STACK)) slots++;  // turns of the node loop with some lane's stack in the global part
+#endif
         }
         // sphere and quad leaves
         {
