@@ -1032,6 +1032,40 @@ def test_axis_parallel_rays_and_origins_on_box_planes(sid):
     assert want["hit"][keep].mean() > 0.2
 
 
+@pytest.mark.parametrize("sid", [8, 6])
+def test_a_few_axis_parallel_rays_among_many_ordinary_ones(sid):
+    """The node test reads a child's near and far bounds by the sign of the direction and skips the reference's min / max
+    per axis, which is exact only for rays whose origin and 1 / direction are finite and non-zero; a wave of the extend
+    kernel switches to the min / max for the rest of the launch once it has fetched a ray of the other kind.  Here one ray in
+    sixty is of that kind (zero, infinite and NaN components, origins on the scenes' planes), scattered over the queue so that
+    waves meet them at different times or never: every record must equal the one-thread-per-ray kernel's field by field, and
+    the ordinary rays must make the reference's decisions as they do without the others in the queue."""
+    w, h = 96, 64
+    gpu, cpu = rt.Scene.builtin(sid, w, h, max_depth=4), ob.OracleScene.builtin(sid, w, h, max_depth=4)
+    rays = np.tile(gpu.primary_rays(np.arange(w * h, dtype=np.uint32), sample=1, seed=0), 3)
+    n = len(rays)
+    rng = np.random.default_rng(23 + sid)
+    special = rng.random(n) < 1.0 / 60.0
+    ns = int(special.sum())
+    planes = np.array({6: [0.0, 555.0, 278.0, 130.0, 265.0, 295.0, 165.0], 8: [0.0, 100.0, 200.0, 123.0, 423.0, 554.0, 278.0, -1000.0]}[sid], np.float32)
+    d = rng.integers(-1, 2, (ns, 3)).astype(np.float32)
+    d[(d == 0).all(axis=1)] = (0, 0, 1)
+    d = np.where((d == 0) & (rng.random((ns, 3)) < 0.3), np.float32(-0.0), d)
+    d = np.where(rng.random((ns, 3)) < 0.05, np.float32(np.inf), d)
+    d = np.where(rng.random((ns, 3)) < 0.02, np.float32(np.nan), d)
+    o = rng.choice(planes, (ns, 3))
+    o = np.where(rng.random((ns, 3)) < 0.5, o + rng.uniform(-50, 50, (ns, 3)).astype(np.float32), o).astype(np.float32)
+    o = np.where(rng.random((ns, 3)) < 0.02, np.float32(np.inf), o)
+    rays["origin"][special], rays["direction"][special] = o, d
+    assert 50 < ns < n // 30
+    a, b = gpu.intersect(rays), gpu.extend(rays)
+    _same_records(a, b)
+    want = cpu.intersect(rays[~special])
+    for got in (a, b):
+        assert np.array_equal(got["hit"][~special], want["hit"])
+        check_hits(got[~special], want)
+
+
 @pytest.mark.parametrize("sid", [0, 6, 8])
 def test_very_long_and_very_short_direction_vectors(sid):
     """Directions are not normalised anywhere on the path (src/camera.rs:318), so t scales inversely with their length: camera
