@@ -493,25 +493,27 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
     if (COUNT) pr.nodes++;
     // byte offsets inside the node array: 32 bytes per axis, the side met first picked by the sign of 1 / direction
     const uint32_t base = cur * (uint32_t)(NODE_FLOATS * sizeof(float));
-    // (the sign bits are taken anew at every node - volatile keeps the compiler from holding three registers for them
-    // through the whole kernel, which has none to spare)
-    uint32_t sx, sy, sz;
-    asm volatile("v_bfe_u32 %0, %1, 31, 1" : "=v"(sx) : "v"(r.inv.x));
-    asm volatile("v_bfe_u32 %0, %1, 31, 1" : "=v"(sy) : "v"(r.inv.y));
-    asm volatile("v_bfe_u32 %0, %1, 31, 1" : "=v"(sz) : "v"(r.inv.z));
-    const uint32_t ax = base | (sx << 4), ay = (base + 32u) | (sy << 4), az = (base + 64u) | (sz << 4);
+    // (the sign bits are taken anew at every node - volatile keeps the compiler from holding registers for them through
+    // the whole kernel, which has none to spare; three instructions per axis: sign bit, | base, ^ 16.  The axes' own
+    // 32 / 64 bytes go on the base pointers, which are scalars)
+    uint32_t ax, ay, az, bx, by, bz;  // a: offset of the bounds met first, b: of those met last
+    asm volatile("v_bfe_u32 %0, %2, 31, 1\n\tv_lshl_or_b32 %0, %0, 4, %3\n\tv_xor_b32 %1, 16, %0" : "=&v"(ax), "=&v"(bx) : "v"(r.inv.x), "v"(base));
+    asm volatile("v_bfe_u32 %0, %2, 31, 1\n\tv_lshl_or_b32 %0, %0, 4, %3\n\tv_xor_b32 %1, 16, %0" : "=&v"(ay), "=&v"(by) : "v"(r.inv.y), "v"(base));
+    asm volatile("v_bfe_u32 %0, %2, 31, 1\n\tv_lshl_or_b32 %0, %0, 4, %3\n\tv_xor_b32 %1, 16, %0" : "=&v"(az), "=&v"(bz) : "v"(r.inv.z), "v"(base));
     float4 nx, fx, ny, fy, nz, fz, q6, q7;
     if (LDS_TOP && cur < src.n_top) {
         lds_bytes* n = (lds_bytes*)src.top;
-        nx = f4(*(const lds_float4v*)(n + ax)); fx = f4(*(const lds_float4v*)(n + (ax ^ 16u)));
-        ny = f4(*(const lds_float4v*)(n + ay)); fy = f4(*(const lds_float4v*)(n + (ay ^ 16u)));
-        nz = f4(*(const lds_float4v*)(n + az)); fz = f4(*(const lds_float4v*)(n + (az ^ 16u)));
+        nx = f4(*(const lds_float4v*)(n + ax)); fx = f4(*(const lds_float4v*)(n + bx));
+        ny = f4(*(const lds_float4v*)(n + 32 + ay)); fy = f4(*(const lds_float4v*)(n + 32 + by));
+        nz = f4(*(const lds_float4v*)(n + 64 + az)); fz = f4(*(const lds_float4v*)(n + 64 + bz));
         q6 = f4(*(const lds_float4v*)(n + (base + 96u))); q7 = f4(*(const lds_float4v*)(n + (base + 112u)));
     } else {
         const char* n = (const char*)src.nodes;
-        nx = *(const float4*)(n + ax); fx = *(const float4*)(n + (ax ^ 16u));
-        ny = *(const float4*)(n + ay); fy = *(const float4*)(n + (ay ^ 16u));
-        nz = *(const float4*)(n + az); fz = *(const float4*)(n + (az ^ 16u));
+        const char* n_y = n + 32;
+        const char* n_z = n + 64;
+        nx = *(const float4*)(n + ax); fx = *(const float4*)(n + bx);
+        ny = *(const float4*)(n_y + ay); fy = *(const float4*)(n_y + by);
+        nz = *(const float4*)(n_z + az); fz = *(const float4*)(n_z + bz);
         q6 = *(const float4*)(n + (base + 96u)); q7 = *(const float4*)(n + (base + 112u));
     }
     const float2v oxy = {r.o.x, r.o.y}, ixy = {r.inv.x, r.inv.y}, zz = {r.o.z, r.inv.z};
