@@ -1203,7 +1203,10 @@ __global__ __launch_bounds__(256) void k_primary_rays(DCamera cam, uint64_t seed
 // one), testing the sphere / quad leaves lanes have arrived at, and testing media.  The medium
 // test is by far the longest, so lanes that arrive at a medium wait there until MEDIUM_MIN of
 // them have gathered (or nothing else is left to do).
-static constexpr int EXTEND_BLOCK = 256;
+#ifndef RT_EXTEND_BLOCK
+#define RT_EXTEND_BLOCK 256
+#endif
+static constexpr int EXTEND_BLOCK = RT_EXTEND_BLOCK;
 
 // LDS of one block: 24 KiB, spent either on 12 stack levels per lane, or - for a tree small
 // enough to be copied into LDS whole - on 8 stack levels and the tree (a copy of only the top
@@ -1237,15 +1240,28 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
         for (uint32_t i = threadIdx.x; i < NODE_FLOAT4S * src.n_top; i += EXTEND_BLOCK) s_top[i] = sc.nodes[i];
         __syncthreads();
     }
+    __shared__ uint32_t s_cursor;  // 64-ray blocks the waves of this thread block have taken so far
+    if (threadIdx.x == 0) s_cursor = 0;
+    __syncthreads();
     const uint32_t n = counts[bounce];
     const uint32_t lane = threadIdx.x & 63;
     // the same value in all lanes of a wave: said so explicitly, which keeps the queue bookkeeping below in scalar registers
     const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t wave = blockIdx.x * (EXTEND_BLOCK / 64) + wave_in_block, n_waves = gridDim.x * (EXTEND_BLOCK / 64);
+    // A thread block owns EXTEND_BLOCK / 64 consecutive 64-ray blocks out of every n_waves of the queue; its waves take them
+    // one at a time from a counter in LDS, so the waves of a thread block finish together (the sum of several waves' work
+    // varies less from thread block to thread block than one wave's does from wave to wave).
+    auto take_block = [&]() -> uint32_t {
+        uint32_t i = 0;
+        if (lane == 0) i = __hip_atomic_fetch_add(&s_cursor, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        constexpr uint32_t W = EXTEND_BLOCK / 64;
+        return (i / W) * n_waves + blockIdx.x * W + (i % W);
+    };
     // Work of this wave: the 64-ray blocks w, w + n_waves, w + 2 n_waves, ... of the queue.  Interleaving
     // spreads expensive image regions over all waves (a contiguous slice per wave does not: the rows of
     // an image differ a lot in cost), with no atomics.
-    uint32_t blk = wave;
+    uint32_t blk = take_block();
     if ((unsigned long long)blk * 64ull >= n) return;
     uint32_t next = blk * 64u;
     uint32_t blk_end = min(n, next + 64u);
@@ -1280,8 +1296,8 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             mine = REF_NONE;
         }
         if (next == blk_end && next < n) {  // block used up: on to this wave's next one
-            unsigned long long nb = ((unsigned long long)blk + n_waves) * 64ull;
-            blk += n_waves;
+            blk = take_block();
+            unsigned long long nb = (unsigned long long)blk * 64ull;
             next = (uint32_t)min(nb, (unsigned long long)n);
             blk_end = (uint32_t)min(nb + 64ull, (unsigned long long)n);
         }
@@ -1916,7 +1932,7 @@ int extend_blocks_per_cu(bool counting, bool generic_media) {
                      : std::min(blocks_of(k_extend<false, false, false>), blocks_of(k_extend<false, true, false>));
     (void)hipGetLastError();
     // a block whose LDS divides the CU's 160 KiB exactly does not get the last slot in practice
-    int by_lds = (int)((160u * 1024u - 1024u) / (2048u * (uint32_t)RT_EXTEND_STACK + 16u));  // 2 KiB per stack level and block
+    int by_lds = (int)((160u * 1024u - 1024u) / (512u * (EXTEND_BLOCK / 64) * (uint32_t)RT_EXTEND_STACK + 32u));  // 512 B per stack level and wave
     return std::min(a, by_lds);
 }
 int tail_blocks_per_cu() {
