@@ -1,0 +1,36 @@
+"""Copies what scripts/final_profiles.sh left under gpurun_out/ into profiles/ and rewrites profiles/traffic.json from the
+new PMC summary.  usage: python scripts/update_profiles.py <tag in gpurun_out, e.g. r02d> <prefix in profiles, e.g. r02_c>"""
+import glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, dst = sys.argv[1], sys.argv[2]
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+shutil.copy(f"{G}/{tag}_bench.json", f"{P}/{dst}_bench.json")
+shutil.copy(f"{G}/{tag}_bench_under_rocprof.json", f"{P}/{dst}_bench_under_rocprof.json")
+stats = sorted(glob.glob(f"{G}/{tag}_kstats/*/*_kernel_stats.csv"), key=os.path.getmtime)[-1]
+shutil.copy(stats, f"{P}/{dst}_kernel_stats_bench.csv")
+shutil.copy(f"{G}/{tag}_pmc_summary.log", f"{P}/{dst}_pmc_summary.json")
+shutil.copy(f"{G}/{tag}_extend_by_bounce.txt", f"{P}/{dst}_extend_by_bounce.txt")
+d = json.load(open(f"{P}/{dst}_pmc_summary.json"))
+t = json.load(open(f"{P}/traffic.json"))
+e = next(v for k, v in d.items() if k.startswith("rt::k_extend<false"))
+segments = t["pipeline"]["segments"]  # of 16 spp of the headline scene: the PMC runs render the same samples
+src = f"profiles/{dst}_pmc_summary.json"
+t["extend"].update({"source": f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, one pipeline, 16 spp of the 4K headline scene; FETCH_SIZE doubled as on gfx950)",
+                    "hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "fetch_bytes": e["fetch_bytes"], "write_bytes": e["write_bytes"], "dispatches": e["dispatches"]})
+hbm = sum(v.get("fetch_bytes", 0) + v.get("write_bytes", 0) for v in d.values())
+t["pipeline"].update({"hbm_bytes_per_segment": round(hbm / segments, 1), "hbm_bytes_per_16spp_step": hbm})
+valu = sum(v["raw"].get("SQ_ACTIVE_INST_VALU", 0) for v in d.values())
+secs = sum(v["seconds_profiled"] for v in d.values())
+t["extend_issue"].update({"source": f"{src} (SQ passes, one pipeline, 16 spp of the 4K headline scene)",
+                          "valu_issue_share": e["valu_issue_share_at_2p4GHz"], "active_lanes_per_valu_inst": e["active_lanes_per_valu_inst"],
+                          "wait_share_of_wave_cycles": e["wait_any_share_of_wave_cycles"],
+                          "valu_insts_per_segment_wave": round(e["raw"]["SQ_INSTS_VALU"] / (segments / 64), 1),
+                          "whole_step_valu_issue_share": round(valu * 4 / (1024 * 2.4e9 * secs), 3)})
+json.dump(t, open(f"{P}/traffic.json", "w"), indent=1)
+b = json.load(open(f"{P}/{dst}_bench.json"))
+print("bench", b["value"], "Msamples/s; extend", b["roofline"]["avg_launch_ms"], "ms per launch, alone", b["roofline"]["alone"]["avg_launch_ms"])
+print("extend (PMC run):", e["seconds_profiled"] * 1e3, "ms,", e["raw"]["SQ_INSTS_VALU"] / 1e9, "G VALU,", e["raw"]["SQ_INSTS_SALU"] / 1e9, "G SALU;", t["extend_issue"])
+for line in open(f"{P}/{dst}_kernel_stats_bench.csv"):
+    if "k_extend<false" in line:
+        print("kernel trace:", line.split('",')[1:4])
+print("under rocprof:", json.load(open(f"{P}/{dst}_bench_under_rocprof.json"))["roofline"]["avg_launch_ms"])
