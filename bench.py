@@ -165,6 +165,11 @@ def other_configs(rt, device, traffic):
 
 def main():
     args = parse_args()
+    # The one JSON line is all this program writes to its standard output: whatever libraries print there (RCCL writes a
+    # version banner when its first communicator comes up) goes to standard error instead.
+    sys.stdout.flush()
+    json_out = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -316,7 +321,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_out, (json.dumps(result) + "\n").encode())
 
 
 if __name__ == "__main__":
