@@ -1273,8 +1273,17 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
     Probe pr;
     uint32_t segs = 0, nhit = 0, slots = 0;
 
-    uint32_t mine = REF_NONE;  // queue slot this lane is working on
-    uint32_t cur = REF_DONE, best = REF_NONE;
+    // State of a lane: cur is REF_NONE while the lane has no ray, REF_DONE when its ray is finished and waits to be written
+    // back, else the reference the ray is at.  Every question the loop asks is then one comparison on cur: inner nodes are
+    // below 2^31, sphere / moving-sphere / quad leaves 0x80000000 .. 0xDFFFFFFF, media 0xE0000000 .. 0xEFFFFFFF (a medium's
+    // reference never has the placed bit), REF_DONE and REF_NONE at the very top.
+    static_assert((REF_LEAF | (KIND_MEDIUM << 29)) == 0xE0000000u && REF_PLACED == 0x10000000u && KIND_MEDIUM == 3u && REF_DONE >= 0xF0000000u,
+                  "the comparisons below spell out the layout of a reference");
+    auto is_inner = [](uint32_t c) { return (int32_t)c >= 0; };
+    auto is_prim = [](uint32_t c) { return (int32_t)c < (int32_t)0xE0000000u; };
+    auto is_medium = [](uint32_t c) { return c - 0xE0000000u < 0x10000000u; };
+    uint32_t mine = 0;  // queue slot this lane is working on (meaningful while cur != REF_NONE)
+    uint32_t cur = REF_NONE, best = REF_NONE;
     float tmax = RT_INF;
     TravRay r;
     BatchMediumKey key{seed, 0, bounce, b};
@@ -1289,11 +1298,11 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
     for (;;) {
         bool moved = false;
         const int refill_min = eager ? 1 : tune.refill_min, inner_min = eager ? 1 : tune.inner_min, medium_min = eager ? 1 : tune.medium_min;
-        if (__ballot(mine != REF_NONE && cur == REF_DONE)) moved = true;
-        if (mine != REF_NONE && cur == REF_DONE) {  // retire
+        if (__ballot(cur == REF_DONE)) moved = true;
+        if (cur == REF_DONE) {  // retire
             hits[mine] = make_uint2(__float_as_uint(tmax), best);
             if (COUNT) { segs++; nhit += (best != REF_NONE); }
-            mine = REF_NONE;
+            cur = REF_NONE;
         }
         if (next == blk_end && next < n) {  // block used up: on to this wave's next one
             blk = take_block();
@@ -1302,21 +1311,20 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             blk_end = (uint32_t)min(nb + 64ull, (unsigned long long)n);
         }
         const uint32_t avail = blk_end - next;
-        const unsigned long long m_idle = __ballot(mine == REF_NONE);
+        const unsigned long long m_idle = __ballot(cur == REF_NONE);
         if (m_idle == ~0ull && avail == 0) break;
         const uint32_t n_refill = min((uint32_t)__popcll(m_idle), avail);
 #if RT_LANE_STATS == 4
         if (COUNT) slots++;
 #endif
-        // lanes with a ray never hold REF_DONE here; leaf kinds: 0, 1 spheres, 2 quads, 3 media
-        unsigned long long m_busy = __ballot(mine != REF_NONE && (cur >> 29) != 7u);  // at an inner node, a sphere or a quad
+        unsigned long long m_busy = __ballot(cur < 0xE0000000u);  // at an inner node, a sphere or a quad
         if (n_refill != 0 && ((int)__popcll(m_idle) >= refill_min || m_busy == 0)) {
             moved = true;
 #if RT_LANE_STATS == 3
             if (COUNT) slots++;
 #endif
             uint32_t rank = (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull));
-            const bool fetch = mine == REF_NONE && rank < avail;
+            const bool fetch = cur == REF_NONE && rank < avail;
             bool odd_ray = false;
             if (fetch) {
                 mine = next + rank;
@@ -1339,15 +1347,14 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
         }
         // inner nodes
         for (;;) {
-            const bool at_inner = mine != REF_NONE && !ref_is_leaf(cur);  // REF_DONE has the leaf bit set
+            const bool at_inner = is_inner(cur);
             const unsigned long long m = __ballot(at_inner);
             if (m == 0) break;
             if ((int)__popcll(m) < inner_min) {
-                const bool parked = mine != REF_NONE && cur != REF_DONE && ref_is_leaf(cur);
-                const unsigned long long m_prim = __ballot(parked && ref_kind(cur) != KIND_MEDIUM);
-                const unsigned long long m_med = __ballot(parked && ref_kind(cur) == KIND_MEDIUM);
+                const unsigned long long m_prim = __ballot(is_prim(cur));
+                const unsigned long long m_med = __ballot(is_medium(cur));
                 if (m_prim != 0 || (int)__popcll(m_med) >= medium_min) break;
-                if (next < n && (int)__popcll(__ballot(mine == REF_NONE || cur == REF_DONE)) >= refill_min) break;
+                if (next < n && (int)__popcll(__ballot(cur >= REF_DONE)) >= refill_min) break;  // lanes free or about to be
             }
             moved = true;
 #if RT_LANE_STATS == 1
@@ -1366,7 +1373,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
         }
         // sphere and quad leaves
         {
-            const bool at_prim = mine != REF_NONE && cur != REF_DONE && ref_is_leaf(cur) && ref_kind(cur) != KIND_MEDIUM;
+            const bool at_prim = is_prim(cur);
 #if RT_LANE_STATS == 2
             if (COUNT && __ballot(at_prim)) slots++;
 #endif
@@ -1379,13 +1386,13 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
         }
         // media: once enough lanes wait at one, or when the wave has nothing else it could do
         {
-            const bool at_medium = mine != REF_NONE && cur != REF_DONE && ref_is_leaf(cur) && ref_kind(cur) == KIND_MEDIUM;
+            const bool at_medium = is_medium(cur);
             const unsigned long long m_med = __ballot(at_medium);
             if (m_med != 0) {
                 bool run = (int)__popcll(m_med) >= medium_min;
                 if (!run) {
-                    const unsigned long long m_other = __ballot(mine != REF_NONE && !at_medium);  // includes finished rays: they free lanes
-                    const bool can_refill = avail > n_refill || (__ballot(mine == REF_NONE) != 0 && next < n);
+                    const unsigned long long m_other = __ballot(cur != REF_NONE) & ~m_med;  // includes finished rays: they free lanes
+                    const bool can_refill = avail > n_refill || (__ballot(cur == REF_NONE) != 0 && next < n);
                     run = m_other == 0 && !can_refill;
                 }
                 if (run) {
