@@ -1,7 +1,7 @@
 #!/bin/bash
 # Register / scratch / occupancy figures of every kernel and device function (from the .s)
 cd "$(dirname "$0")/../raytracing_amd/csrc"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -S --cuda-device-only -o /tmp/rt_kernels.s rt_kernels.hip 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -S --cuda-device-only -o /tmp/rt_kernels.s rt_kernels.hip 2>/dev/null
 python3 - <<'PY'
 import re
 s=open('/tmp/rt_kernels.s').read()

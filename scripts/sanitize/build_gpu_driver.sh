@@ -8,7 +8,7 @@ O=$R/variants/san
 mkdir -p $O
 CL=/opt/rocm/lib/llvm/bin/clang++
 HOSTSAN="-Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer"
-DEV="-std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DRT_BVH_WIDTH=4"
+DEV="-std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -DRT_BVH_WIDTH=4"
 hipcc -O1 -g $DEV $HOSTSAN -c $R/raytracing_amd/csrc/rt_api.hip -o $O/rt_api.o
 hipcc -O3 $DEV $HOSTSAN -c $R/raytracing_amd/csrc/rt_kernels.hip -o $O/rt_kernels.o
 for f in $R/scripts/sanitize/gpu_host_san.cpp $R/raytracing_amd/host/{raytracing,scenes,capi,image_io}.cpp $R/raytracing_amd/csrc/rt_bvh.cpp; do
