@@ -1128,6 +1128,12 @@ RT_D void store_thr(float* base, uint32_t i, float4 v) {
     float* p = base + 3 * (size_t)i;
     p[0] = v.x; p[1] = v.y; p[2] = v.z;
 }
+// dst = v as one 16-byte store of the four components.  (Assigned as structs, a path's radiance and its next ray are written
+// component by component; the compiler then merges the component stores of the branches that end a path with those of the
+// branch that continues it into one block with a pointer that is either - and the next ray lives in scratch memory, written
+// through flat stores.)
+typedef float float4n __attribute__((ext_vector_type(4)));
+RT_D void put4(float4* dst, const float4& v) { *(float4n*)dst = float4n{v.x, v.y, v.z, v.w}; }
 
 // get_ray + pixel_sample_square + defocus_disk_sample (src/camera.rs:311-320,368-380).
 // Draw order on the camera stream: jitter x, jitter y, [disk trials], time.
@@ -1446,7 +1452,7 @@ RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, ui
     float3 T = f3(th);
     if (h.y == REF_NONE) {  // src/camera.rs:347-349
         float3 c = T * cam.background;
-        radiance[path] = make_float4(c.x, c.y, c.z, 0.0f);
+        put4(&radiance[path], make_float4(c.x, c.y, c.z, 0.0f));
         return false;
     }
     const uint4* meta = leaf_meta(sc, h.y);
@@ -1465,17 +1471,17 @@ RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, ui
     ScatterResult r = shade_hit<TEXTURES>(sc, rec, g, d, rng, lds_perlin);
     if (!r.scattered) {  // src/camera.rs:354-355
         float3 c = T * r.emitted;
-        radiance[path] = make_float4(c.x, c.y, c.z, 0.0f);
+        put4(&radiance[path], make_float4(c.x, c.y, c.z, 0.0f));
         return false;
     }
     if (bounce + 1 >= cam.max_depth) {  // depth exhausted, src/camera.rs:342
-        radiance[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        put4(&radiance[path], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         return false;
     }
-    float3 nT = T * r.attenuation + r.emitted;  // src/camera.rs:360
+    // throughput * attenuation + emitted (src/camera.rs:360), component by component
+    nt = make_float4(T.x * r.attenuation.x + r.emitted.x, T.y * r.attenuation.y + r.emitted.y, T.z * r.attenuation.z + r.emitted.z, 0.0f);
     no = make_float4(g.p.x, g.p.y, g.p.z, ro.w);
     nd = make_float4(r.dir.x, r.dir.y, r.dir.z, rd.w);
-    nt = make_float4(nT.x, nT.y, nT.z, 0.0f);
     return true;
 }
 
@@ -1575,7 +1581,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
         for (int k = 0; k < SHADE_PER_THREAD; ++k) {
             const uint32_t e = k * SHADE_BLOCK + tid;
             bool alive = false;
-            float4 no, nd, nt;
+            float4 no = make_float4(0, 0, 0, 0), nd = no, nt = no;
             if (e < tile_n) {
                 const uint32_t i = tile + s_order[e];
                 if (e < first_textured) {
@@ -1592,8 +1598,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(DScene sc, DCamera cam, B
                 slot0 = __shfl(slot0, (int)leader, 64);
                 if (alive) {
                     uint32_t slot = slot0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                    s_out[0][slot] = no;
-                    s_out[1][slot] = nd;
+                    put4(&s_out[0][slot], no);
+                    put4(&s_out[1][slot], nd);
                     s_out_thr[3 * slot] = nt.x;
                     s_out_thr[3 * slot + 1] = nt.y;
                     s_out_thr[3 * slot + 2] = nt.z;
@@ -1656,7 +1662,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (uint32_t first = blockIdx.x * blockDim.x; first < n; first += gridDim.x * blockDim.x) {
         const uint32_t j = first + threadIdx.x;
         bool alive = false;
-        float4 no, nd, nt;
+        float4 no = make_float4(0, 0, 0, 0), nd = no, nt = no;
         if (j < n) {
             const uint32_t i = tex_list[j];
             alive = shade_one<true>(sc, cam, b, seed, bounce, ray_o[i], ray_d[i], load_thr(thr, i), hits[i], radiance, no, nd, nt, lds_perlin);
@@ -1672,8 +1678,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (alive) {
             uint32_t slot = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             for (uint32_t w2 = 0; w2 < wave; ++w2) slot += s_wave_count[w2];
-            out_o[slot] = no;
-            out_d[slot] = nd;
+            put4(&out_o[slot], no);
+            put4(&out_d[slot], nd);
             store_thr(out_thr, slot, nt);
         }
         __syncthreads();
@@ -1732,7 +1738,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_tail(DScene sc, DCamera cam, Bat
             global_leaves<false, GENERIC>(sc, r, tmax, best, key, pr);
             st.sp = 0;
             walk_tree<false, GENERIC>(sc, r, tmax, best, key, st, pr);
-            float4 no, nd, nt;
+            float4 no = make_float4(0, 0, 0, 0), nd = no, nt = no;
             // (shade_one ends the path - and writes its radiance - at a miss, a light, an absorbed ray or the depth limit)
             have = shade_one<TEXTURES, true>(sc, cam, b, seed, bounce, ro, rd, th, make_uint2(__float_as_uint(tmax), best), radiance, no, nd, nt);
             ro = no; rd = nd; th = nt;
