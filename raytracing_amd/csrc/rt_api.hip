@@ -527,7 +527,9 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         c->extend_blocks_generic = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::min(per_cu, per_cu_generic);
         c->extend_blocks_counting_generic =
             (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::min(std::min(per_cu, per_cu_generic), per_cu_counting_generic);
-        c->tail_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::max(1, rt::tail_blocks_per_cu());
+        int tail_per_cu = std::max(1, rt::tail_blocks_per_cu());
+        if (const char* e = getenv("RT_AMD_TAIL_BLOCKS_PER_CU")) tail_per_cu = std::max(1, atoi(e));  // tuning experiments only
+        c->tail_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)tail_per_cu;
         if (const char* e = getenv("RT_AMD_EXTEND_TUNING"))  // "inner,refill,medium": tuning experiments only
             sscanf(e, "%d,%d,%d", &c->tune.inner_min, &c->tune.refill_min, &c->tune.medium_min);
         if (const char* e = getenv("RT_AMD_TAIL_RAYS")) c->tail_rays = (uint32_t)std::max(1, atoi(e));  // tuning experiments only
