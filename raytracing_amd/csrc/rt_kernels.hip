@@ -35,6 +35,15 @@ namespace rt {
 static constexpr float RT_INF = __builtin_huge_valf();
 static constexpr int STACK_SIZE = (int)TRAVERSAL_STACK_ENTRIES;  // rt_scene_create rejects trees that could need more
 
+// *p as one 16-byte load.  (Read as a struct, a record is four scalar loads to the compiler, which then moves the one for a
+// component that is used later - a quad's D, a sphere's radius - down to that use: one more memory round trip in the middle
+// of a leaf test.)
+typedef float float4n __attribute__((ext_vector_type(4)));
+RT_D float4 get4(const float4* p) {
+    const float4n v = *(const float4n*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // ---------------------------------------------------------------------------
 // leaf tests
 // ---------------------------------------------------------------------------
@@ -81,8 +90,8 @@ RT_D void quad_alpha_beta(float4 qq, float4 uu, float4 vv, float3 p, float& alph
 
 // Quad::hit (src/hittable.rs:372-398) with the per-quad constants N, D, w hoisted:
 // closed interval tmin <= t <= tmax, 0 <= alpha, beta <= 1.
-RT_D bool quad_root(const float4* __restrict__ q4, float3 o, float3 d, float tmin, float tmax, float& t) {
-    float4 nd = q4[0];
+// nd: the quad's first record (N, D), read by the caller - together with the leaf's placement where there is one.
+RT_D bool quad_root(const float4* __restrict__ q4, float4 nd, float3 o, float3 d, float tmin, float tmax, float& t) {
     float3 N = f3(nd);
     float denom = dot3(N, d);
     if (fabsf(denom) < 1e-8f) return false;
@@ -141,7 +150,7 @@ RT_D bool leaf_root_in_leaf_space(const DScene& sc, uint32_t ref, float3 o, floa
         return sphere_root(c, s.w, o, d, a, tmin, tmax, t);
     } else {
         if (COUNT) pr.quads++;
-        return quad_root(sc.quads + 4 * (size_t)idx, o, d, tmin, tmax, t);
+        return quad_root(sc.quads + 4 * (size_t)idx, get4(sc.quads + 4 * (size_t)idx), o, d, tmin, tmax, t);
     }
 }
 
@@ -154,11 +163,11 @@ RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float ti
         float3 c;
         const float4* xf;
         if (kind == KIND_SPHERE) {
-            s = sc.spheres[idx];
+            s = get4(sc.spheres + idx);
             c = f3(s);
             xf = sc.sphere_xf + 2 * (size_t)idx;
         } else {
-            s = sc.moving[2 * (size_t)idx];
+            s = get4(sc.moving + 2 * (size_t)idx);
             c = f3(s) + time * f3(sc.moving[2 * (size_t)idx + 1]);  // MovingSphere::hit, src/hittable.rs:310
             xf = sc.moving_xf + 2 * (size_t)idx;
         }
@@ -170,8 +179,9 @@ RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float ti
     } else {
         if (COUNT) pr.quads++;
         const float4* q4 = sc.quads + 4 * (size_t)idx;
+        const float4 nd = get4(q4);  // on its way while the placement is read and applied
         if (ref_placed(ref)) ray_to_object(sc.quad_xf[2 * (size_t)idx], sc.quad_xf[2 * (size_t)idx + 1], o, d);
-        return quad_root(q4, o, d, tmin, tmax, t);
+        return quad_root(q4, nd, o, d, tmin, tmax, t);
     }
 }
 
@@ -222,6 +232,20 @@ RT_D bool boundary_root(const DScene& sc, const DMedium& m, float3 o, float3 d, 
     }
     t = hi;
     return any;
+}
+
+// A medium's record as three 16-byte loads that go out together (read field by field, the compiler fetches each field where
+// it is first used: the density a memory round trip after the boundary sphere, in the middle of the longest test there is).
+typedef uint32_t uint4n __attribute__((ext_vector_type(4)));
+RT_D DMedium load_medium(const DMedium* p) {
+    static_assert(sizeof(DMedium) == 48 && offsetof(DMedium, sphere) == 32, "three 16-byte groups");
+    const uint4n a = *(const uint4n*)p, b = *((const uint4n*)p + 1);
+    const float4n s = *((const float4n*)p + 2);
+    DMedium m;
+    m.first_boundary = a.x; m.n_boundary = a.y; m.neg_inv_density = __uint_as_float(a.z); m.phase_material = a.w;
+    m.prim_id = b.x; m.single_sphere = b.y; m.shared_xform = b.z; m._pad = b.w;
+    m.sphere = make_float4(s.x, s.y, s.z, s.w);
+    return m;
 }
 
 // What a medium needs to start its random stream: (seed, pixel, sample) of the path and the
@@ -284,7 +308,7 @@ template <bool COUNT, bool GENERIC, class Key>
 RT_D bool medium_root(const DScene& sc, uint32_t idx, float3 o, float3 d, float time, float a, float tmin, float tmax,
                       const Key& key, float& t, Probe& pr) {
     if (COUNT) pr.media++;
-    DMedium m = sc.media[idx];
+    DMedium m = load_medium(sc.media + idx);
     float t1, t2;
     if (!GENERIC || m.single_sphere) {
         // Boundary = one sphere in world space: the two queries share oc, half_b, c and the square root.
@@ -646,7 +670,7 @@ RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_
             const float4 s = sc.spheres[ref_index(ref)];
             const uint32_t next = g + 1 < sc.n_global ? sc.global_refs[g + 1] : REF_NONE;
             if (next != REF_NONE && ref_kind(next) == KIND_MEDIUM) {
-                const DMedium m = sc.media[ref_index(next)];
+                const DMedium m = load_medium(sc.media + ref_index(next));
                 if (m.single_sphere && m.sphere.x == s.x && m.sphere.y == s.y && m.sphere.z == s.z && m.sphere.w == s.w) {
                     if (COUNT) { pr.spheres += 3; pr.media++; }
                     float near_root, far_root;
@@ -1132,7 +1156,6 @@ RT_D void store_thr(float* base, uint32_t i, float4 v) {
 // component by component; the compiler then merges the component stores of the branches that end a path with those of the
 // branch that continues it into one block with a pointer that is either - and the next ray lives in scratch memory, written
 // through flat stores.)
-typedef float float4n __attribute__((ext_vector_type(4)));
 RT_D void put4(float4* dst, const float4& v) { *(float4n*)dst = float4n{v.x, v.y, v.z, v.w}; }
 
 // get_ray + pixel_sample_square + defocus_disk_sample (src/camera.rs:311-320,368-380).
