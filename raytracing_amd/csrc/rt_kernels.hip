@@ -1357,16 +1357,15 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             bool odd_ray = false;
             if (fetch) {
                 mine = next + rank;
-                float4 ro = ray_o[mine], rd = ray_d[mine];
+                // the ray and its starting hit record in one round trip: all three loads go out before anything waits
+                const float4 ro = get4(ray_o + mine), rd = get4(ray_d + mine);
+                uint2 h0 = make_uint2(__float_as_uint(RT_INF), REF_NONE);
+                if (first_leaves_done) h0 = hits[mine];
+                asm volatile("" : "+v"(h0.x), "+v"(h0.y));  // (keeps the compiler from moving that load below the divisions)
                 key.path = __float_as_uint(rd.w);
                 r = make_trav_ray(f3(ro), f3(rd), ro.w, RENDER_TMIN);
-                tmax = RT_INF;
-                best = REF_NONE;
-                if (first_leaves_done) {
-                    uint2 h0 = hits[mine];
-                    tmax = __uint_as_float(h0.x);
-                    best = h0.y;
-                }
+                tmax = __uint_as_float(h0.x);
+                best = h0.y;
                 st.sp = 0;
                 cur = root;
                 odd_ray = r.odd;
