@@ -97,12 +97,12 @@ RT_D bool quad_root(const float4* __restrict__ q4, float4 nd, float3 o, float3 d
     if (fabsf(denom) < 1e-8f) return false;
     float tt = (nd.w - dot3(N, o)) / denom;
     if (!(tmin <= tt && tt <= tmax)) return false;
-    // alpha first, beta only when alpha is inside: fewer values are live at a time (the traversal kernel has few registers to spare)
-    const float4 qq = q4[1], vv = q4[3];
-    const float3 h = (o + tt * d) - f3(qq), w = f3(qq.w, q4[2].w, vv.w);
+    // the three remaining records in one round trip
+    const float4 qq = get4(q4 + 1), uu = get4(q4 + 2), vv = get4(q4 + 3);
+    const float3 h = (o + tt * d) - f3(qq), w = f3(qq.w, uu.w, vv.w);
     const float alpha = dot3(w, cross3(h, f3(vv)));
     if (!(0.0f <= alpha && alpha <= 1.0f)) return false;
-    const float beta = dot3(w, cross3(f3(q4[2]), h));
+    const float beta = dot3(w, cross3(f3(uu), h));
     if (!(0.0f <= beta && beta <= 1.0f)) return false;
     t = tt;
     return true;
