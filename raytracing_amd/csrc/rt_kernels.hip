@@ -793,16 +793,18 @@ RT_D HitGeom resolve_hit(const DScene& sc, uint32_t ref, const uint4& m0, float3
     }
     const bool placed = ref_placed(ref);
     float4 rot = make_float4(0, 0, 0, 0), off = rot;
+    // (each kind works on its own copy of the ray, made after its loads have gone out: a copy made up here would make every
+    // load below wait for the ray's direction to arrive)
     if (kind == KIND_QUAD) {
         const float4* q4 = sc.quads + 4 * (size_t)idx;
-        float4 nd = q4[0], qq = q4[1], uu = q4[2], vv = q4[3];
-        if (placed) {
-            rot = sc.quad_xf[2 * (size_t)idx]; off = sc.quad_xf[2 * (size_t)idx + 1];
-            ray_to_object(rot, off, o, d);
-        }
-        g.p = o + t * d;
+        float4 nd = get4(q4), qq = get4(q4 + 1), uu = get4(q4 + 2), vv = get4(q4 + 3);
+        if (placed) { rot = get4(sc.quad_xf + 2 * (size_t)idx); off = get4(sc.quad_xf + 2 * (size_t)idx + 1); }
+        float3 oq = o, dq = d;
+        asm volatile("" : "+v"(oq.x), "+v"(oq.y), "+v"(oq.z), "+v"(dq.x), "+v"(dq.y), "+v"(dq.z));  // (the copy is made here, not earlier)
+        if (placed) ray_to_object(rot, off, oq, dq);
+        g.p = oq + t * dq;
         quad_alpha_beta(qq, uu, vv, g.p, g.u, g.v);
-        set_face_normal(g, d, f3(nd));
+        set_face_normal(g, dq, f3(nd));
     } else {
         float3 c;
         float r;
@@ -816,13 +818,13 @@ RT_D HitGeom resolve_hit(const DScene& sc, uint32_t ref, const uint4& m0, float3
             c = f3(s0) + time * f3(s1); r = s0.w;
             xf = sc.moving_xf + 2 * (size_t)idx;
         }
-        if (placed) {
-            rot = xf[0]; off = xf[1];
-            ray_to_object(rot, off, o, d);
-        }
-        g.p = o + t * d;
+        if (placed) { rot = get4(xf); off = get4(xf + 1); }
+        float3 os = o, ds = d;
+        asm volatile("" : "+v"(os.x), "+v"(os.y), "+v"(os.z), "+v"(ds.x), "+v"(ds.y), "+v"(ds.z));  // (the copy is made here, not earlier)
+        if (placed) ray_to_object(rot, off, os, ds);
+        g.p = os + t * ds;
         float3 outward = (1.0f / r) * (g.p - c);
-        set_face_normal(g, d, outward);
+        set_face_normal(g, ds, outward);
         g.uv_dir = outward;  // object space, as get_sphere_uv sees it (src/hittable.rs:284)
         g.uv_ready = false;
     }
@@ -1468,13 +1470,16 @@ __global__ __launch_bounds__(256) void k_first_leaves(DScene sc, BatchInfo b, ui
 template <bool TEXTURES, bool PLAIN_CHECKERS = !TEXTURES>
 RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, uint64_t seed, uint32_t bounce, float4 ro, float4 rd, float4 th,
                     uint2 h, float4* __restrict__ radiance, float4& no, float4& nd, float4& nt, PerlinLds lds_perlin = PerlinLds{nullptr, nullptr, false}) {
-    const uint32_t id = __float_as_uint(rd.w);  // (sample of the batch << pixel_bits) | pixel of the batch
-    const uint32_t s_local = id >> b.pixel_bits, pixel_local = id & ((1u << b.pixel_bits) - 1u);
-    const uint32_t path = s_local * b.n_pixels + pixel_local;  // slot in the radiance array
+    // The path's id, (sample of the batch << pixel_bits) | pixel of the batch, travels in the direction's fourth lane.  What
+    // is derived from it is worked out where it is used and not up here: this way nothing waits for the direction before the
+    // loads of the leaf's records (which only need the reference) have gone out - one memory round trip instead of two.
+    auto s_local_of = [&]() { return __float_as_uint(rd.w) >> b.pixel_bits; };
+    auto pixel_local_of = [&]() { return __float_as_uint(rd.w) & ((1u << b.pixel_bits) - 1u); };
+    auto path_of = [&]() { return s_local_of() * b.n_pixels + pixel_local_of(); };  // slot in the radiance array
     float3 T = f3(th);
     if (h.y == REF_NONE) {  // src/camera.rs:347-349
         float3 c = T * cam.background;
-        put4(&radiance[path], make_float4(c.x, c.y, c.z, 0.0f));
+        put4(&radiance[path_of()], make_float4(c.x, c.y, c.z, 0.0f));
         return false;
     }
     const uint4* meta = leaf_meta(sc, h.y);
@@ -1489,15 +1494,15 @@ RT_D bool shade_one(const DScene& sc, const DCamera& cam, const BatchInfo& b, ui
         rec.tex_kind = RT_TEX_SOLID;  // the texture has been evaluated
     }
     Rng rng;
-    rng.init(path_key(seed, b.first_pixel + pixel_local, b.first_sample + s_local), bounce, STREAM_SCATTER);
+    rng.init(path_key(seed, b.first_pixel + pixel_local_of(), b.first_sample + s_local_of()), bounce, STREAM_SCATTER);
     ScatterResult r = shade_hit<TEXTURES>(sc, rec, g, d, rng, lds_perlin);
     if (!r.scattered) {  // src/camera.rs:354-355
         float3 c = T * r.emitted;
-        put4(&radiance[path], make_float4(c.x, c.y, c.z, 0.0f));
+        put4(&radiance[path_of()], make_float4(c.x, c.y, c.z, 0.0f));
         return false;
     }
     if (bounce + 1 >= cam.max_depth) {  // depth exhausted, src/camera.rs:342
-        put4(&radiance[path], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        put4(&radiance[path_of()], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         return false;
     }
     // throughput * attenuation + emitted (src/camera.rs:360), component by component
