@@ -111,6 +111,43 @@ def test_multi_entry_point_with_more_shares_than_rows():
         buf.free()
 
 
+@pytest.mark.parametrize("n_ctx", [2, 3])
+def test_back_to_back_sample_split_calls_without_synchronizing(n_ctx):
+    """Four sample-split calls in a row, three samples each (every context has a share), nothing waited for in between,
+    every context on a stream of its own and the head's stream busy with other work when the calls are made: the other
+    contexts are then whole calls ahead of the head, and their next share must not land in the buffer the head has yet
+    to add (the analogue of the rows of src/camera.rs:282-304 all finishing before the image is read)."""
+    import torch
+    streams = [torch.cuda.Stream() for _ in range(n_ctx)]
+    scenes = [rt.Scene.builtin(8, W, H) for _ in range(n_ctx)]
+    for s, st in zip(scenes, streams):
+        s.set_stream(st.cuda_stream)
+    head, others = scenes[0], scenes[1:]
+    buf = DeviceBuffer(head)
+    # work that keeps the head's stream busy: a render of a larger image into a buffer nobody reads
+    busy = rt.Scene.builtin(8, 640, 360)
+    busy.set_stream(streams[0].cuda_stream)
+    busy.render_accumulate_device(busy.device_accumulator, 1, 8, seed=1)
+    per_call, calls = 3, 4
+    for k in range(calls):
+        head.render_accumulate_multi(others, buf.ptr, 1 + per_call * k, per_call, seed=SEED, split=_abi.SPLIT_SAMPLES)
+    head.synchronize()
+    torch.cuda.synchronize()
+    got = buf.get()
+    want = np.zeros((H, W, 4), np.float32)
+    for k in range(calls):
+        first, count = _share(per_call, 0, n_ctx)
+        assert count > 0
+        want = _one_gpu(1 + per_call * k + first, count, start=want)
+        for i in range(1, n_ctx):
+            first, count = _share(per_call, i, n_ctx)
+            assert count > 0
+            want[..., :3] += _one_gpu(1 + per_call * k + first, count)[..., :3]
+    assert np.array_equal(got, want), "every call's shares, summed in GPU order, call after call"
+    buf.free()
+    busy.close()
+
+
 def test_multi_entry_point_across_gpus():
     n = _device_count()
     if n < 2:
