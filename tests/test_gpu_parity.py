@@ -372,6 +372,40 @@ def test_image_statistics_match_reference_random_numbers(sid, spp):
         assert abs(c - ref) <= 3.0 * abs(a - b) + 0.005 * ref + 1e-6, (ch, a, b, c)
 
 
+def _statistical_gates(gpu, cpu_a, cpu_b, spp):
+    """GPU image against two CPU images of the same sample count that used the reference's random numbers (all three are
+    sums over spp samples).  Returns (rmse, noise) of the sqrt-encoded images after checking the bias gate: per channel, the
+    GPU image's mean must lie within 0.5 % + 3 sigma of the mean of the two CPU images, sigma being the standard deviation of
+    such a mean as the per-pixel differences of the two CPU images estimate it."""
+    noise = np.sqrt(np.mean((enc(cpu_a, spp) - enc(cpu_b, spp)) ** 2))
+    rmse = max(np.sqrt(np.mean((enc(gpu, spp) - enc(cpu_a, spp)) ** 2)), np.sqrt(np.mean((enc(gpu, spp) - enc(cpu_b, spp)) ** 2)))
+    n_pix = gpu.shape[0] * gpu.shape[1]
+    for ch in range(3):
+        a, b, c = cpu_a[..., ch].astype(np.float64) / spp, cpu_b[..., ch].astype(np.float64) / spp, gpu[..., ch].astype(np.float64) / spp
+        per_pixel = np.std(a - b) / np.sqrt(2.0)             # noise of one pixel of one image
+        sigma = per_pixel / np.sqrt(n_pix) * np.sqrt(1.5)    # of (GPU mean) - (mean of the two CPU means)
+        ref = 0.5 * (a.mean() + b.mean())
+        assert abs(c.mean() - ref) <= 3.0 * sigma + 0.005 * ref + 1e-7, (ch, a.mean(), b.mean(), c.mean(), sigma)
+    return rmse, noise
+
+
+@pytest.mark.parametrize("sid", [0, 6, 8, 100])
+def test_whole_image_against_the_reference_random_numbers_at_1024_samples(sid):
+    """RaytracingCamera::render as hdr_render uses it (src/camera.rs:107-122): 96 x 54 pixels, 1024 samples per pixel, the GPU's
+    counter-based random numbers against the reference's per-row xoshiro256++ stream on the CPU (all host threads).  Gates:
+    RMSE of the sqrt-encoded images <= 1.15 x the RMSE between two CPU renders with different sample numbers, and the
+    per-channel mean within 0.5 % + 3 sigma (the first four columns are left out: see the 48 x 48 test above)."""
+    w, h, spp = 96, 54, 1024
+    scene = rt.Scene.builtin(sid, w, h)
+    oracle = ob.OracleScene.builtin(sid, w, h)
+    scene.render_samples(spp)
+    gpu = scene.accumulator()[:, 4:]
+    cpu_a = oracle.render(spp, first_sample=1, mode=ob.RNG_XOSHIRO)[:, 4:]
+    cpu_b = oracle.render(spp, first_sample=spp + 1, mode=ob.RNG_XOSHIRO)[:, 4:]
+    rmse, noise = _statistical_gates(gpu, cpu_a, cpu_b, spp)
+    assert rmse <= 1.15 * noise, (rmse, noise)
+
+
 @pytest.mark.parametrize("sid,spp", [(0, 2048), (6, 4096), (8, 4096)])
 def test_high_sample_count_image_rmse(sid, spp):
     """Book-1 scene, Cornell box and the Book-2 final scene (small images), thousands of samples per pixel on both sides
@@ -385,8 +419,7 @@ def test_high_sample_count_image_rmse(sid, spp):
     gpu = scene.accumulator()[:, 4:]
     cpu_a = oracle.render(spp, first_sample=1, mode=ob.RNG_XOSHIRO)[:, 4:]
     cpu_b = oracle.render(spp, first_sample=spp + 1, mode=ob.RNG_XOSHIRO)[:, 4:]
-    noise = np.sqrt(np.mean((enc(cpu_a, spp) - enc(cpu_b, spp)) ** 2))
-    rmse = np.sqrt(np.mean((enc(gpu, spp) - enc(cpu_a, spp)) ** 2))
+    rmse, noise = _statistical_gates(gpu, cpu_a, cpu_b, spp)
     assert rmse <= 1.15 * noise and (sid != 0 or rmse <= 0.01), (rmse, noise)
 
 
