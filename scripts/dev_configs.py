@@ -34,6 +34,7 @@ for name in (sys.argv[1:] or list(CONFIGS)):
     dt = (time.time() - t0) / calls
     seg = cnt["segments"] / cnt["samples"]
     print(f"{name}: scene {sid} {w}x{h} depth {depth}, {spp} spp per call: {dt * 1e3:.1f} ms -> {w * h * spp / dt / 1e6:.1f} Msamples/s, "
-          f"{w * h * spp * seg / dt / 1e6:.0f} Mrays/s ({seg:.2f} segments per sample, {cnt['node_visits'] / cnt['segments']:.1f} node visits per segment); "
+          f"{w * h * spp * seg / dt / 1e6:.0f} Mrays/s ({seg:.2f} segments per sample, {cnt['node_visits'] / cnt['segments']:.2f} node visits, {cnt['sphere_tests'] / cnt['segments']:.2f} sphere tests, "
+          f"{cnt['quad_tests'] / cnt['segments']:.2f} quad tests per segment, deepest stack {cnt['max_stack']}); "
           f"host scene build {t_host:.2f} s, BVH {info['bvh_nodes']} nodes depth {info['bvh_depth']} in {info['build_seconds']:.2f} s, "
           f"{info['device_bytes'] / 1e6:.1f} MB on the GPU", flush=True)

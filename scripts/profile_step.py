@@ -5,6 +5,7 @@ sys.path.insert(0, ROOT)
 import raytracing_amd as rt
 w, h, spp, steps = 3840, 2160, int(os.environ.get("SPP", "4")), int(os.environ.get("STEPS", "2"))
 scene = rt.Scene.builtin(8, w, h, max_depth=25)
+scene.set_pipelines(int(os.environ.get("PIPES", "2")))
 for i in range(steps):
     scene.render_samples(spp)
 scene.synchronize()
