@@ -360,7 +360,8 @@ typedef struct rt_bvh_report {
     uint32_t violations;       /* 0 for a correct tree */
     float sah_cost;            /* sum over inner children and leaves of area / root area */
     uint32_t stack_need;       /* traversal stack entries needed in the worst case (rt_scene_create accepts <= 64) */
-    uint32_t _pad;
+    float packed_surface_ratio; /* mean surface of a child's box in the kernels' 64-byte node (8-bit grid coordinates) over
+                                 * the surface of the box itself: >= 1, the price of the grid in extra box hits */
 } rt_bvh_report;
 int rt_bvh_build_check(const float* boxes, uint32_t n, rt_bvh_report* out);
 
@@ -370,21 +371,34 @@ int rt_bvh_build_check(const float* boxes, uint32_t n, rt_bvh_report* out);
  * for every pixel, acc[pixel] += sum over those samples of the path radiance.
  * acc is width*height*4 floats, row-major, row 0 on top, lane 3 untouched
  * (the reference's Vec<f32x4> acc_colours, src/camera.rs:25).  Random numbers
- * are a pure function of (seed, pixel, sample, bounce), so the result does not
- * are the same whatever the batch size, the scheduling or the split of samples
- * over GPUs: images are bit-identical across batch sizes, pipelines, row
- * ranges and consecutive calls on one buffer, and equal up to the order of the
- * f32 additions when per-GPU buffers of different sample ranges are summed.
+ * are a pure function of (seed, pixel, sample, bounce), so images do not
+ * depend on the batch size, the scheduling or the split over GPUs:
+ * bit-identical across batch sizes, pipelines, row ranges and consecutive
+ * calls on one buffer, and equal up to the order of the f32 additions when
+ * per-GPU buffers of different sample ranges are summed.
  * Blocking; acc_host is read and written on the host.  The buffer is uploaded
  * (beside the render), accumulated into on the GPU and downloaded on every
- * call.  The context keeps the device copy's memory and keeps the caller's
- * buffer registered (page-locked) with the HIP runtime for as long as the same
- * buffer keeps being passed; before freeing such a buffer call
- * rt_ctx_release_host_buffer (or destroy the context). */
+ * call; the context keeps the device copy's memory.  Nothing about acc_host
+ * outlives the call unless rt_ctx_set_host_buffer_pinning asked for it. */
 int rt_render_accumulate(rt_scene* scene, const rt_camera_desc* cam,
                          uint64_t seed, uint32_t first_sample,
                          uint32_t n_samples, float* acc_host);
+/* on != 0: rt_render_accumulate registers (page-locks) the caller's buffer
+ * with the HIP runtime and keeps it registered for as long as the same
+ * pointer and size keep being passed (copies then run at the link's rate and
+ * beside kernels).  The caller takes on a lifetime obligation with it: call
+ * rt_ctx_release_host_buffer (or destroy the context) BEFORE freeing or
+ * reallocating such a buffer - the library recognises the buffer by address
+ * and size only.  Default 0: no registration, nothing to release; callers
+ * that want the fast copies without the obligation allocate the buffer with
+ * rt_host_buffer_create. */
+int rt_ctx_set_host_buffer_pinning(rt_ctx* ctx, int on);
 int rt_ctx_release_host_buffer(rt_ctx* ctx);
+/* Free and total device memory of the context's GPU in bytes, as the HIP
+ * runtime reports them now (what the allocating entry points size their
+ * batches by; also the way to check that a call has allocated nothing).
+ * No counterpart in the reference. */
+int rt_ctx_memory_info(rt_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* Same with the accumulation buffer resident on the GPU; enqueues on the
  * context's stream and returns without waiting. */
 int rt_render_accumulate_device(rt_scene* scene, const rt_camera_desc* cam,

@@ -58,7 +58,7 @@ class RtSceneInfo(C.Structure):
 
 class RtBvhReport(C.Structure):
     _fields_ = [("nodes", C.c_uint32), ("depth", C.c_uint32), ("width", C.c_uint32), ("leaves_found", C.c_uint32),
-                ("violations", C.c_uint32), ("sah_cost", C.c_float), ("stack_need", C.c_uint32), ("_pad", C.c_uint32)]
+                ("violations", C.c_uint32), ("sah_cost", C.c_float), ("stack_need", C.c_uint32), ("packed_surface_ratio", C.c_float)]
 
 
 class Leaf(C.Structure):
@@ -119,7 +119,9 @@ RT_ABI = {
     "rt_scene_get_info": (C.c_int, [_P, C.POINTER(RtSceneInfo)]),
     "rt_bvh_build_check": (C.c_int, [_FP, _U32, C.POINTER(RtBvhReport)]),
     "rt_render_accumulate": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
+    "rt_ctx_set_host_buffer_pinning": (C.c_int, [_P, C.c_int]),
     "rt_ctx_release_host_buffer": (C.c_int, [_P]),
+    "rt_ctx_memory_info": (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rt_render_accumulate_device": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),
     "rt_render_accumulate_rows_device": (C.c_int, [_P, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _U32, _U32, _P]),
     "rt_render_accumulate_multi": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.POINTER(RtCameraDesc), _U64, _U32, _U32, _P]),

@@ -136,6 +136,7 @@ struct rt_ctx {
     size_t d_acc_cache_bytes = 0;
     void* pinned_ptr = nullptr;
     size_t pinned_bytes = 0;
+    bool pin_host_buffers = false;  // rt_ctx_set_host_buffer_pinning
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_upload = nullptr;
 
@@ -433,8 +434,9 @@ constexpr uint32_t TAIL_MAX_BATCH = 1u << 24;
 constexpr uint32_t COUNTS_SEEN_MAX = 1024;
 uint32_t tail_start_for(rt_ctx* c, const rt_scene* sc, const rt_camera_desc* cam, uint64_t paths, bool learn) {
     const uint32_t max_depth = cam->max_depth;
+    if (c->counters_on) return max_depth;  // the tail kernel has no counting build: with the work counters on, every bounce runs the kernels that count
     if (c->tail_start >= 0) return std::min<uint32_t>((uint32_t)c->tail_start, max_depth);
-    if (c->counters_on || paths > TAIL_MAX_BATCH) return max_depth;
+    if (paths > TAIL_MAX_BATCH) return max_depth;
     auto& seen = c->seen;
     if (learn && seen.scene == sc && seen.width == cam->width && seen.height == cam->height && seen.max_depth == max_depth && seen.paths == paths) {
         if (seen.n != 0 && hipEventQuery(c->ev_counts) == hipSuccess) {
@@ -517,7 +519,9 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     {
         int per_cu = rt::extend_blocks_per_cu(false, false), per_cu_counting = rt::extend_blocks_per_cu(true, false);
         int per_cu_generic = rt::extend_blocks_per_cu(false, true), per_cu_counting_generic = rt::extend_blocks_per_cu(true, true);
-        if (const char* e = getenv("RT_AMD_EXTEND_BLOCKS_PER_CU")) per_cu = atoi(e);  // tuning experiments only
+#ifdef RT_DEV_KNOBS  // development builds (make DEV=1): environment overrides for tuning experiments, not part of the product
+        if (const char* e = getenv("RT_AMD_EXTEND_BLOCKS_PER_CU")) per_cu = atoi(e);
+#endif
         if (per_cu < 1) per_cu = 4;
         if (per_cu_counting < 1) per_cu_counting = 3;
         c->extend_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)per_cu;
@@ -528,14 +532,18 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         c->extend_blocks_counting_generic =
             (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::min(std::min(per_cu, per_cu_generic), per_cu_counting_generic);
         int tail_per_cu = std::max(1, rt::tail_blocks_per_cu());
-        if (const char* e = getenv("RT_AMD_TAIL_BLOCKS_PER_CU")) tail_per_cu = std::max(1, atoi(e));  // tuning experiments only
+#ifdef RT_DEV_KNOBS
+        if (const char* e = getenv("RT_AMD_TAIL_BLOCKS_PER_CU")) tail_per_cu = std::max(1, atoi(e));
+#endif
         c->tail_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)tail_per_cu;
-        if (const char* e = getenv("RT_AMD_EXTEND_TUNING"))  // "inner,refill,medium": tuning experiments only
+#ifdef RT_DEV_KNOBS
+        if (const char* e = getenv("RT_AMD_EXTEND_TUNING"))  // "inner,refill,medium"
             sscanf(e, "%d,%d,%d", &c->tune.inner_min, &c->tune.refill_min, &c->tune.medium_min);
-        if (const char* e = getenv("RT_AMD_TAIL_RAYS")) c->tail_rays = (uint32_t)std::max(1, atoi(e));  // tuning experiments only
-        if (const char* e = getenv("RT_AMD_PIPES")) c->n_pipes = std::min(MAX_PIPES, std::max(1, atoi(e)));  // A/B experiments only
+        if (const char* e = getenv("RT_AMD_TAIL_RAYS")) c->tail_rays = (uint32_t)std::max(1, atoi(e));
+        if (const char* e = getenv("RT_AMD_PIPES")) c->n_pipes = std::min(MAX_PIPES, std::max(1, atoi(e)));
         if (getenv("RT_AMD_VERBOSE"))
             fprintf(stderr, "[rt_amd] extend kernel: %d blocks per CU, grid %u; %d pipeline(s)\n", per_cu, c->extend_blocks, c->n_pipes);
+#endif
     }
     hipError_t e = hipSuccess;
     if (device_id < MAX_DEVICES && scratch_base[device_id] == nullptr) {
@@ -1003,22 +1011,35 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
     sc->d.generic_media = media_are_single_spheres ? 0u : 1u;
     auto bail = [&](int code) { rt_scene_destroy(sc); return code; };
 
+#if RT_BVH_WIDTH == 4
+    // the kernels' form of a node (rt_bvh.h, PackedNode): 64 bytes, the children's boxes on the node's own 8-bit grid
+    std::vector<float4> nodes(4 * (size_t)bvh.n_nodes);
+    {
+        const std::vector<rt::PackedNode> packed = rt::pack_nodes(bvh);
+        if (rt::check_packed_nodes(bvh, packed).violations != 0) return bail(fail(RT_ERR_HIP, "internal error: a packed BVH node does not contain its child"));
+        static_assert(sizeof(rt::PackedNode) == 4 * sizeof(float4), "a packed node is four 16-byte groups");
+        if (!packed.empty()) std::memcpy(nodes.data(), packed.data(), packed.size() * sizeof(rt::PackedNode));
+    }
+#else
     std::vector<float4> nodes(bvh.nodes.size() / 4);
     if (!nodes.empty()) std::memcpy(nodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
-#if RT_BVH_WIDTH == 4
-    // the kernels' layout of a node (rt_device.h): bounds by axis and side, four children each, from the builder's by child
-    for (uint32_t i = 0; i < bvh.n_nodes; ++i) {
-        const float* q = &bvh.nodes[rt::NODE_FLOATS * (size_t)i];
-        float4* n = &nodes[8 * (size_t)i];
-        n[0] = make_float4(q[0], q[4], q[8], q[12]);    // min.x
-        n[1] = make_float4(q[2], q[6], q[10], q[14]);   // max.x
-        n[2] = make_float4(q[1], q[5], q[9], q[13]);    // min.y
-        n[3] = make_float4(q[3], q[7], q[11], q[15]);   // max.y
-        n[4] = make_float4(q[16], q[18], q[20], q[22]); // min.z
-        n[5] = make_float4(q[17], q[19], q[21], q[23]); // max.z
-    }
 #endif
     if ((e = upload(sc, nodes, &sc->d.nodes))) return bail(e);
+    {   // The reference's own box of every leaf that sits in world space (Hittable::calc_aabb, src/hittable.rs:158-178): the
+        // kernels test it - as AABBx2::hit would (src/math/aabb.rs:127-167) - before they accept a hit on such a leaf, because
+        // that test decides in the reference whether the leaf is looked at at all.
+        auto boxes_of = [&](const std::vector<Aabb>& boxes, const float4** out) -> int {
+            std::vector<float4> flat(2 * boxes.size());
+            for (size_t i = 0; i < boxes.size(); ++i) {
+                flat[2 * i] = make_float4(boxes[i].mn[0], boxes[i].mn[1], boxes[i].mn[2], 0.0f);
+                flat[2 * i + 1] = make_float4(boxes[i].mx[0], boxes[i].mx[1], boxes[i].mx[2], 0.0f);
+            }
+            return upload(sc, flat, out);
+        };
+        if ((e = boxes_of(sphere_box, &sc->d.sphere_boxes))) return bail(e);
+        if ((e = boxes_of(moving_box, &sc->d.moving_boxes))) return bail(e);
+        if ((e = boxes_of(quad_box, &sc->d.quad_boxes))) return bail(e);
+    }
     if ((e = upload(sc, spheres, &sc->d.spheres))) return bail(e);
     if ((e = upload(sc, sphere_meta, &sc->d.sphere_meta))) return bail(e);
     if ((e = upload(sc, moving, &sc->d.moving))) return bail(e);
@@ -1151,7 +1172,7 @@ int rt_bvh_build_check(const float* boxes, uint32_t n, rt_bvh_report* out) {
         prims[i].exact = 1;
     }
     FlatBvh bvh = build_bvh(prims, 0);
-    *out = rt_bvh_report{bvh.n_nodes, bvh.max_depth, (uint32_t)rt::BVH_WIDTH, 0, 0, 0.0f, bvh.stack_need, 0};
+    *out = rt_bvh_report{bvh.n_nodes, bvh.max_depth, (uint32_t)rt::BVH_WIDTH, 0, 0, 0.0f, bvh.stack_need, 1.0f};
     if (n == 0) { out->violations = bvh.root == REF_NONE ? 0 : 1; return RT_OK; }
     if (n == 1) { out->leaves_found = 1; out->violations = bvh.root == make_leaf(KIND_SPHERE, 0, false) ? 0 : 1; return RT_OK; }
     struct Box3 { float mn[3], mx[3]; };
@@ -1209,6 +1230,13 @@ int rt_bvh_build_check(const float* boxes, uint32_t n, rt_bvh_report* out) {
         }
     }
     for (uint32_t i = 0; i < bvh.n_nodes; ++i) if (!node_seen[i]) ++violations;
+#if RT_BVH_WIDTH == 4
+    {   // the 64-byte form the kernels read: every child's grid box must contain the child's box
+        const rt::PackCheck pc = rt::check_packed_nodes(bvh, rt::pack_nodes(bvh));
+        violations += pc.violations;
+        out->packed_surface_ratio = (float)pc.mean_surface_ratio;
+    }
+#endif
     out->leaves_found = found;
     out->violations = violations + (found != n ? 1u : 0u);
     out->sah_cost = (float)cost;
@@ -1423,6 +1451,23 @@ int rt_render_accumulate_device_noalloc(rt_scene* sc, const rt_camera_desc* cam,
     return render_rows(sc, cam, seed, first_sample, n_samples, 0, cam->height, d_acc, &q);
 }
 
+int rt_ctx_set_host_buffer_pinning(rt_ctx* c, int on) {
+    if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    int e = set_device(c);
+    if (e) return e;
+    c->pin_host_buffers = on != 0;
+    if (!c->pin_host_buffers) release_host_buffer(c);
+    return RT_OK;
+}
+
+int rt_ctx_memory_info(rt_ctx* c, size_t* free_bytes, size_t* total_bytes) {
+    if (!c || !free_bytes || !total_bytes) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    int e = set_device(c);
+    if (e) return e;
+    HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+    return RT_OK;
+}
+
 int rt_ctx_release_host_buffer(rt_ctx* c) {
     if (!c) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
     int e = set_device(c);
@@ -1450,11 +1495,13 @@ int rt_render_accumulate(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed,
     }
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (!c->ev_upload) HIP_TRY(hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
-    // The caller's buffer is page-locked once, for as long as the same buffer keeps coming (copies from and to pageable
+    // When the caller has asked for it, the buffer is page-locked once, for as long as the same buffer keeps coming (copies from and to pageable
     // memory run at a fraction of the link's rate, and only copies from page-locked memory run beside kernels).  Not
     // every system lets the runtime lock memory it did not allocate; rt_host_buffer_create hands out memory that is
     // page-locked from the start, and pageable memory still works, only slower.
-    if (c->pinned_ptr != (void*)acc_host || c->pinned_bytes != bytes) {
+    if (!c->pin_host_buffers) {
+        release_host_buffer(c);
+    } else if (c->pinned_ptr != (void*)acc_host || c->pinned_bytes != bytes) {
         release_host_buffer(c);
         hipPointerAttribute_t attr;
         const bool locked_already = hipPointerGetAttributes(&attr, acc_host) == hipSuccess && attr.type == hipMemoryTypeHost;
@@ -1545,6 +1592,10 @@ int rt_render_accumulate_multi(rt_scene* const* scenes, int n_gpus, int split, c
             HIP_TRY(hipMemsetAsync(c->d_partial, 0, bytes, c->stream));
             if (count && (e = render_rows(scenes[i], cam, seed, first_sample + first, count, 0, cam->height, c->d_partial, nullptr))) return e;
             if ((e = set_device(c))) return e;
+            // peer_in[i] is kept from call to call and the call returns without waiting: the additions of the previous
+            // call (on GPU 0's stream, which may lag behind this GPU's) must have read it before the new share lands in it.
+            // ev_multi_ready was recorded on that stream after them.
+            HIP_TRY(hipStreamWaitEvent(c->stream, c0->ev_multi_ready, 0));
             HIP_TRY(hipMemcpyPeerAsync(c0->peer_in[(size_t)i], c0->device, c->d_partial, c->device, bytes, c->stream));
         } else {
             // its rows of the image as they are now, the new samples on top, and back: exactly what one GPU would have computed

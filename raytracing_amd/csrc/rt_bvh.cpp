@@ -409,4 +409,111 @@ FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads) {
     return out;
 }
 
+#if RT_BVH_WIDTH == 4
+namespace {
+// child k of the builder's wide node (layout: fold_to_four)
+struct ChildBox { double mn[3], mx[3]; bool valid; uint32_t ref; };
+ChildBox builder_child(const FlatBvh& bvh, uint32_t node, int k) {
+    const float* n = &bvh.nodes[NODE_FLOATS * (size_t)node];
+    ChildBox c;
+    c.valid = n[NODE_SLACK_AT + k] > 0.0f;  // NaN: empty slot
+    c.mn[0] = n[4 * k]; c.mn[1] = n[4 * k + 1]; c.mx[0] = n[4 * k + 2]; c.mx[1] = n[4 * k + 3];
+    c.mn[2] = n[16 + 2 * k]; c.mx[2] = n[17 + 2 * k];
+    std::memcpy(&c.ref, &n[NODE_REFS_AT + k], 4);
+    return c;
+}
+// What a grid box must leave around the child's own box on an axis where the node spans `extent` and holds coordinates of
+// magnitude up to `mag`: far more than the kernels' rounding (a few units in the last place of the extent and of the
+// coordinates), far less than a grid step (extent / 255).
+double pack_margin(double extent, double mag) { return std::ldexp(extent, -16) + std::ldexp(mag, -20) + 1e-30; }
+}  // namespace
+
+std::vector<PackedNode> pack_nodes(const FlatBvh& bvh) {
+    std::vector<PackedNode> out(bvh.n_nodes);
+    for (uint32_t i = 0; i < bvh.n_nodes; ++i) {
+        ChildBox c[4];
+        int first_valid = -1;
+        for (int k = 0; k < 4; ++k) {
+            c[k] = builder_child(bvh, i, k);
+            if (c[k].valid && first_valid < 0) first_valid = k;
+        }
+        PackedNode& p = out[i];
+        uint32_t* qlo[3] = {&p.qlo_x, &p.qlo_y, &p.qlo_z};
+        uint32_t* qhi[3] = {&p.qhi_x, &p.qhi_y, &p.qhi_z};
+        float* step[3] = {&p.step_x, &p.step_y, &p.step_z};
+        for (int a = 0; a < 3; ++a) {
+            double lo = DBL_MAX, hi = -DBL_MAX;
+            for (int k = 0; k < 4; ++k)
+                if (c[k].valid) { lo = std::min(lo, c[k].mn[a]); hi = std::max(hi, c[k].mx[a]); }
+            if (first_valid < 0) lo = hi = 0.0;
+            const double m = pack_margin(hi - lo, std::max(std::fabs(lo), std::fabs(hi)));
+            const float lo_f = std::nextafterf((float)(lo - m), -INFINITY);
+            const double top = hi + m;
+            float s = std::nextafterf((float)((top - (double)lo_f) / 255.0), INFINITY);
+            while ((double)lo_f + 255.0 * (double)s < top) s = std::nextafterf(s, INFINITY);
+            p.lo[a] = lo_f;
+            *step[a] = s;
+            uint32_t lo_bytes = 0, hi_bytes = 0;
+            for (int k = 0; k < 4; ++k) {
+                int ql = 255, qh = 0;  // empty slot: inside out
+                if (c[k].valid) {
+                    ql = (int)std::floor((c[k].mn[a] - m - (double)lo_f) / (double)s);
+                    ql = std::min(255, std::max(0, ql));
+                    while (ql > 0 && (double)lo_f + ql * (double)s > c[k].mn[a] - m) --ql;
+                    qh = (int)std::ceil((c[k].mx[a] + m - (double)lo_f) / (double)s);
+                    qh = std::min(255, std::max(0, qh));
+                    while (qh < 255 && (double)lo_f + qh * (double)s < c[k].mx[a] + m) ++qh;
+                }
+                lo_bytes |= (uint32_t)ql << (8 * k);
+                hi_bytes |= (uint32_t)qh << (8 * k);
+            }
+            *qlo[a] = lo_bytes;
+            *qhi[a] = hi_bytes;
+        }
+        for (int k = 0; k < 4; ++k) p.ref[k] = c[k].valid ? c[k].ref : (first_valid >= 0 ? c[first_valid].ref : 0xFFFFFFFFu);
+    }
+    return out;
+}
+
+PackCheck check_packed_nodes(const FlatBvh& bvh, const std::vector<PackedNode>& packed) {
+    PackCheck r{0, 0.0};
+    if (packed.size() != bvh.n_nodes) { r.violations = 1; return r; }
+    double ratio_sum = 0.0;
+    size_t ratio_n = 0;
+    for (uint32_t i = 0; i < bvh.n_nodes; ++i) {
+        const PackedNode& p = packed[i];
+        const uint32_t qlo[3] = {p.qlo_x, p.qlo_y, p.qlo_z}, qhi[3] = {p.qhi_x, p.qhi_y, p.qhi_z};
+        const double step[3] = {p.step_x, p.step_y, p.step_z};
+        int first_valid = -1;
+        for (int k = 0; k < 4; ++k) {
+            const ChildBox c = builder_child(bvh, i, k);
+            if (c.valid && first_valid < 0) first_valid = k;
+            double own[3], grid[3];
+            for (int a = 0; a < 3; ++a) {
+                const int ql = (int)((qlo[a] >> (8 * k)) & 255u), qh = (int)((qhi[a] >> (8 * k)) & 255u);
+                if (!c.valid) {
+                    if (ql != 255 || qh != 0) ++r.violations;
+                    continue;
+                }
+                const double g0 = (double)p.lo[a] + ql * step[a], g1 = (double)p.lo[a] + qh * step[a];
+                // half of what pack_nodes leaves: the check's own arithmetic is exact, the kernels' is not
+                const double half_m = 0.5 * std::ldexp(c.mx[a] - c.mn[a], -16);
+                if (!(g0 <= c.mn[a] - half_m) || !(g1 >= c.mx[a] + half_m) || !(step[a] > 0.0) || !std::isfinite(step[a])) ++r.violations;
+                own[a] = c.mx[a] - c.mn[a];
+                grid[a] = g1 - g0;
+            }
+            if (c.valid) {
+                if (p.ref[k] != c.ref) ++r.violations;
+                const double so = own[0] * own[1] + own[1] * own[2] + own[2] * own[0], sg = grid[0] * grid[1] + grid[1] * grid[2] + grid[2] * grid[0];
+                if (so > 0.0) { ratio_sum += sg / so; ++ratio_n; }
+            }
+        }
+        for (int k = 0; k < 4; ++k)
+            if (!builder_child(bvh, i, k).valid && first_valid >= 0 && p.ref[k] != builder_child(bvh, i, first_valid).ref) ++r.violations;
+    }
+    r.mean_surface_ratio = ratio_n ? ratio_sum / (double)ratio_n : 1.0;
+    return r;
+}
+#endif
+
 }  // namespace rt

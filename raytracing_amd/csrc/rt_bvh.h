@@ -40,4 +40,31 @@ constexpr uint32_t TRAVERSAL_STACK_ENTRIES = 64;
 // Builds over `prims` (reordered in place).  threads <= 0 picks a default.
 FlatBvh build_bvh(std::vector<BuildPrim>& prims, int threads);
 
+// The form of a four-child node that the kernels read: 64 bytes, the children's boxes as 8-bit coordinates on a grid of
+// 255 steps per axis that spans the node's own box (a little more than the union of its children).  A child's box on
+// that grid always contains the child's box as the builder made it, with a margin that covers the rounding of the
+// kernels' arithmetic on the grid coordinates: the node test decides which children to LOOK at, never what is hit.
+//   lo[a] + q * step[a]   is the coordinate of grid line q (0..255) on axis a
+//   qlo[a], qhi[a]        four bytes each: byte k is child k's lower / upper grid line on axis a
+//   ref[k]                child k's reference (rt_device.h); an empty slot repeats child 0's reference under a box
+//                         that is inside out (qlo = 255, qhi = 0), which no ray with a usable direction enters
+// Half the bytes of the builder's own node per visit: what the extend kernel's tree walk is bound by is the rate at
+// which a CU's vector memory path serves per-lane 16-byte reads at scattered addresses (about one per cycle).
+struct PackedNode {
+    float lo[3];
+    float step_x;
+    float step_y, step_z;
+    uint32_t qlo_x, qhi_x;
+    uint32_t qlo_y, qhi_y, qlo_z, qhi_z;
+    uint32_t ref[4];
+};
+static_assert(sizeof(PackedNode) == 64, "four 16-byte groups");
+#if RT_BVH_WIDTH == 4
+std::vector<PackedNode> pack_nodes(const FlatBvh& bvh);
+// Children of packed nodes whose grid box does not contain the builder's box with the margin pack_nodes promises (0 for
+// a correct packing), and the mean ratio of a child's grid box surface to its own box surface (how much the grid costs).
+struct PackCheck { uint32_t violations; double mean_surface_ratio; };
+PackCheck check_packed_nodes(const FlatBvh& bvh, const std::vector<PackedNode>& packed);
+#endif
+
 }  // namespace rt

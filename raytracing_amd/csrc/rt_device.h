@@ -35,18 +35,25 @@ RT_HD bool ref_placed(uint32_t r) { return (r & REF_PLACED) != 0; }
 
 // ---------------------------------------------------------------------------
 // HBM layout (all arrays 16-byte aligned, one or more float4 per element):
-//   nodes   8 x float4 per node of four children (128 B), bounds by axis and side so that a ray reads the side it
-//           meets first / last of all four children with one 16-byte load each, picked by the sign of its direction:
-//             [0] = min.x of children 0..3   [1] = max.x   [2] = min.y   [3] = max.y   [4] = min.z   [5] = max.z
-//             [6]   = bits(child references)                    [7] = slack of each child
-//           (the builder's own array, rt_bvh.h, is by child; rt_scene_create transposes it)
-//           slack multiplies the child's exit distance: 1 for a leaf whose box is the
-//           reference's own AABB (tested exactly), 1 + 2 ulp for conservative boxes, NaN for an
-//           empty slot (never entered: no comparison with NaN holds).  With RT_BVH_WIDTH=2 a node is 4 x float4:
+//   nodes   4 x float4 per node of four children (64 B, rt_bvh.h PackedNode): the node's own box as an origin and a
+//           step per axis, and the children's boxes as 8-bit coordinates on that grid, by axis and side (four
+//           children to a 32-bit word), so that a ray picks the words of the sides it meets first / last by the sign
+//           of its direction:
+//             [0] = lo.x, lo.y, lo.z, step.x      [1] = step.y, step.z, bytes(lower x), bytes(upper x)
+//             [2] = bytes(lower y), bytes(upper y), bytes(lower z), bytes(upper z)      [3] = child references
+//           A child's grid box contains the child's box with a margin; the node test is conservative (it decides
+//           what is looked at, never what is hit).  A leaf whose box is the reference's own AABB has that box in
+//           *_boxes, and a hit on it only counts if the reference's box test of that box passes - the test that
+//           decides in the reference's tree whether the leaf is looked at.  An empty slot repeats the first child's
+//           reference under a box that is inside out.  (The builder's array, rt_bvh.h, keeps f32 boxes by child;
+//           rt_scene_create packs it.)  With RT_BVH_WIDTH=2 a node is 4 x float4 of f32 boxes:
 //             [0] = l.min.xy, l.max.xy   [1] = r.min.xy, r.max.xy
 //             [2] = l.min.z, l.max.z, r.min.z, r.max.z   [3] = bits(left), bits(right), slacks
-//           Nodes are numbered breadth-first for the first levels (the part of the tree every
-//           ray walks sits in a few KB at the start of the array), depth-first below.
+//           (slack multiplies the child's exit distance: 1 for a leaf whose box is the reference's own AABB, 1 + 2 ulp
+//           for conservative boxes.)  Nodes are numbered breadth-first for the first levels (the part of the tree
+//           every ray walks sits in a few KB at the start of the array), depth-first below.
+//   *_boxes 2 x float4 per sphere, moving sphere and quad: min.xyz, max.xyz of the leaf's own AABB as the reference
+//           computes it (Hittable::calc_aabb, src/hittable.rs:158-178); meaningful for leaves that are not placed
 //   spheres 1 x float4: centre.xyz, radius                      (16 B)
 //   moving  2 x float4: centre0.xyz, radius | dcentre.xyz, 0     (32 B)
 //   quads   4 x float4: N.xyz, D | q.xyz, w.x | u.xyz, w.y | v.xyz, w.z  (64 B)
@@ -134,6 +141,10 @@ struct DScene {
     const float4* sphere_xf;
     const float4* moving_xf;
     const float4* quad_xf;
+    // the reference's own AABB of leaf i at [2 i] (min), [2 i + 1] (max)
+    const float4* sphere_boxes;
+    const float4* moving_boxes;
+    const float4* quad_boxes;
     const DMaterial* materials;
     const DTexture* textures;
     const DImage* images;

@@ -91,19 +91,26 @@ RT_D void quad_alpha_beta(float4 qq, float4 uu, float4 vv, float3 p, float& alph
 // Quad::hit (src/hittable.rs:372-398) with the per-quad constants N, D, w hoisted:
 // closed interval tmin <= t <= tmax, 0 <= alpha, beta <= 1.
 // nd: the quad's first record (N, D), read by the caller - together with the leaf's placement where there is one.
-RT_D bool quad_root(const float4* __restrict__ q4, float4 nd, float3 o, float3 d, float tmin, float tmax, float& t) {
+// own_box (may be NULL): the quad's own AABB, min and max; a hit then only counts if own_box_test passes for it (see
+// leaf_root).  inv = 1 / d, used by that test only.
+RT_D bool own_box_test(float4 mn, float4 mx, float3 o, float3 inv, float lo, float hi);
+RT_D bool quad_root(const float4* __restrict__ q4, float4 nd, float3 o, float3 d, float tmin, float tmax, float& t,
+                    const float4* __restrict__ own_box = nullptr, float3 inv = make_float3(0.0f, 0.0f, 0.0f)) {
     float3 N = f3(nd);
     float denom = dot3(N, d);
     if (fabsf(denom) < 1e-8f) return false;
     float tt = (nd.w - dot3(N, o)) / denom;
     if (!(tmin <= tt && tt <= tmax)) return false;
-    // the three remaining records in one round trip
+    // the three remaining records (and the quad's own box) in one round trip
     const float4 qq = get4(q4 + 1), uu = get4(q4 + 2), vv = get4(q4 + 3);
+    float4 mn = make_float4(0, 0, 0, 0), mx = mn;
+    if (own_box) { mn = get4(own_box); mx = get4(own_box + 1); }
     const float3 h = (o + tt * d) - f3(qq), w = f3(qq.w, uu.w, vv.w);
     const float alpha = dot3(w, cross3(h, f3(vv)));
     if (!(0.0f <= alpha && alpha <= 1.0f)) return false;
     const float beta = dot3(w, cross3(f3(uu), h));
     if (!(0.0f <= beta && beta <= 1.0f)) return false;
+    if (own_box && !own_box_test(mn, mx, o, inv, tmin, tmax)) return false;
     t = tt;
     return true;
 }
@@ -154,34 +161,54 @@ RT_D bool leaf_root_in_leaf_space(const DScene& sc, uint32_t ref, float3 o, floa
     }
 }
 
-template <bool COUNT>
-RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float time, float a, float tmin, float tmax, float& t, Probe& pr) {
+// OWN_BOX: the leaf is a child of a tree node (not part of a medium's boundary).  With four-child nodes the node test is
+// conservative, so the reference's test of the leaf's own box (AABBx2::hit, src/math/aabb.rs:127-167, on the box of
+// Hittable::calc_aabb) is made here for every hit on a leaf that sits in world space: in the reference's tree that test
+// decides whether the leaf is looked at at all, so a hit only counts where it passes.  It nearly always does (a ray that
+// hits a primitive crosses its box); where roundings make the two disagree - a sphere smaller than the spacing of f32
+// numbers at its distance, a quad's thin box far along a ray - the reference's outcome is the one reproduced.  A placed
+// leaf's box is tested in object space by the reference, inside its Move / RotateY, and is not reproduced.  The box
+// travels with the leaf's record (one round trip).  inv = 1 / d.
+template <bool COUNT, bool OWN_BOX = false>
+RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float time, float a, float tmin, float tmax, float& t, Probe& pr,
+                    float3 inv = make_float3(0.0f, 0.0f, 0.0f)) {
     const uint32_t kind = ref_kind(ref), idx = ref_index(ref);
+#ifdef RT_NO_OWN_BOX  // timing experiments only (development builds): results differ where the reference's box test fails
+    const bool own_box = false;
+#else
+    const bool own_box = OWN_BOX && RT_BVH_WIDTH == 4 && !ref_placed(ref);
+#endif
     if (kind != KIND_QUAD) {  // a sphere, still or moving: the two kinds share one copy of the root computation
         if (COUNT) pr.spheres++;
         float4 s;
         float3 c;
         const float4* xf;
+        float4 mn = make_float4(0, 0, 0, 0), mx = mn;
+        // (each kind reads its own arrays inside its branch: a pointer chosen by kind and used after the branches is a table
+        // in scratch memory and a flat load to the compiler)
         if (kind == KIND_SPHERE) {
             s = get4(sc.spheres + idx);
+            if (own_box) { mn = get4(sc.sphere_boxes + 2 * (size_t)idx); mx = get4(sc.sphere_boxes + 2 * (size_t)idx + 1); }
             c = f3(s);
             xf = sc.sphere_xf + 2 * (size_t)idx;
         } else {
             s = get4(sc.moving + 2 * (size_t)idx);
-            c = f3(s) + time * f3(sc.moving[2 * (size_t)idx + 1]);  // MovingSphere::hit, src/hittable.rs:310
+            const float4 dc = get4(sc.moving + 2 * (size_t)idx + 1);
+            if (own_box) { mn = get4(sc.moving_boxes + 2 * (size_t)idx); mx = get4(sc.moving_boxes + 2 * (size_t)idx + 1); }
+            c = f3(s) + time * f3(dc);  // MovingSphere::hit, src/hittable.rs:310
             xf = sc.moving_xf + 2 * (size_t)idx;
         }
         if (ref_placed(ref)) {
             ray_to_object(xf[0], xf[1], o, d);
             a = dot3(d, d);
         }
-        return sphere_root(c, s.w, o, d, a, tmin, tmax, t);
+        return sphere_root(c, s.w, o, d, a, tmin, tmax, t) && (!own_box || own_box_test(mn, mx, o, inv, tmin, tmax));
     } else {
         if (COUNT) pr.quads++;
         const float4* q4 = sc.quads + 4 * (size_t)idx;
         const float4 nd = get4(q4);  // on its way while the placement is read and applied
         if (ref_placed(ref)) ray_to_object(sc.quad_xf[2 * (size_t)idx], sc.quad_xf[2 * (size_t)idx + 1], o, d);
-        return quad_root(q4, nd, o, d, tmin, tmax, t);
+        return quad_root(q4, nd, o, d, tmin, tmax, t, own_box ? sc.quad_boxes + 2 * (size_t)idx : nullptr, inv);
     }
 }
 
@@ -430,7 +457,7 @@ struct NodeSource {
     uint32_t n_top;
 };
 typedef float float2v __attribute__((ext_vector_type(2)));
-static constexpr uint32_t NODE_FLOAT4S = NODE_FLOATS / 4;
+static constexpr uint32_t NODE_FLOAT4S = 4;  // 64 bytes per node, whichever the width (rt_device.h)
 
 // One inner node: slab-tests both children, continues with the nearer one and stacks the
 // other.  Returns the next reference (inner node, leaf, or REF_DONE).
@@ -478,14 +505,20 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
     return pop_next(st, tmax);
 }
 #else
-// Four children per node.  Each child's slab test is the two-child one above, with one shortcut: a node stores its
-// children's bounds one axis and one side at a time (min.x of the four children, max.x, min.y, ...), so a ray reads,
-// per axis, the bounds it meets first and the bounds it meets last straight from the side its direction's sign names.
-// For min <= max and a finite non-zero 1 / direction, (near - o) * inv <= (far - o) * inv holds in floating point as
-// it does in the reals (subtraction and multiplication round monotonically), so the pair is exactly the
-// (min(t0, t1), max(t0, t1)) of AABBx2::hit (src/math/aabb.rs:127-167) with no min / max spent on it.  Rays for which
-// that does not hold (a zero, infinite or NaN direction component: t0 or t1 can be NaN, and which one the reference's
-// NaN-dropping min / max keep depends on both) take the min / max as well: `odd`, the same for every lane of the wave.
+// Four children per node, 64 bytes per node (rt_bvh.h, PackedNode): the children's boxes are 8-bit coordinates on a grid
+// that spans the node's own box, q in 0..255 on axis a standing for lo[a] + q * step[a].  A child's slab distances come
+// straight from the grid coordinates: t = q * (step / d) + (lo - o) / d, one fused multiply-add per bound after two
+// multiplications and a subtraction per axis and node.  The words that hold the four children's lower / upper coordinates
+// of an axis are swapped where the direction is negative, so the first is what the ray meets first on that axis and no
+// min / max is spent on ordering the pair.
+//
+// This test is conservative, never exact: a child's grid box contains the child's box with a margin of 2^-16 of the
+// node's extent (pack_nodes), against roundings here of a few 2^-24 of that extent, and the entry distance is shrunk by
+// 2^-18 of itself, against roundings of a few 2^-24 of the distances.  It decides which children are looked at.  What
+// is hit is decided by the leaves' own tests, and for a leaf that sits in world space by the reference's test of the
+// leaf's own box on top (leaf_box_passes below), as in the reference's tree.  NaN distances (0 * inf for a direction
+// component that is zero) drop out of the max / min reductions, as they do out of simd_min / simd_max in the reference,
+// and so never cull a child.
 // The children that are hit are ordered by entry distance with a five-exchange sorting network (entry distances
 // are positive, so their bit patterns order like the numbers; a child that is missed gets the
 // key ~0), the nearest is continued with and the others are stacked farthest first.
@@ -495,112 +528,99 @@ RT_D void order2(uint32_t& ka, uint32_t& ra, uint32_t& kb, uint32_t& rb) {
     ka = k0; kb = k1; ra = r0; rb = r1;
 }
 typedef __attribute__((address_space(3))) const char lds_bytes;
-// (a - b[SEL]) * c[SEL2] for both halves of a, each operation rounded once: packed subtract and multiply that take one
-// half of their second operand for both lanes (operand selection is part of the instruction; the compiler would copy
-// the half into a register pair of its own instead, and the extend kernel has no registers to spare).
-template <int SEL>
-RT_D float2v pk_sub_half(float2v a, float2v b) {
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const uint4v lds_uint4v;
+// a * b[SEL_B] + c[SEL_C] for both halves of a, fused: a packed multiply-add that takes one half of its second and third
+// operand for both lanes (operand selection is part of the instruction; written out, the compiler would copy the halves
+// into register pairs of their own, and the extend kernel has no registers to spare).
+template <int SEL_B, int SEL_C>
+RT_D float2v pk_fma_half(float2v a, float2v b, float2v c) {
     float2v d;
-    if (SEL == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    if (SEL_B == 0 && SEL_C == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    else if (SEL_B == 1 && SEL_C == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
-template <int SEL>
-RT_D float2v pk_mul_half(float2v a, float2v b) {
-    float2v d;
-    if (SEL == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
+static constexpr float NODE_TEST_SHRINK = 1.0f - 0x1p-18f;   // what the entry distance of a child's grid box is multiplied by
 template <bool COUNT, bool LDS_TOP, class Stack>
 RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr, bool odd) {
     if (COUNT) pr.nodes++;
-    // byte offsets inside the node array: 32 bytes per axis, the side met first picked by the sign of 1 / direction
-    const uint32_t base = cur * (uint32_t)(NODE_FLOATS * sizeof(float));
-    // (the sign bits are taken anew at every node - volatile keeps the compiler from holding registers for them through
-    // the whole kernel, which has none to spare; three instructions per axis: sign bit, | base, ^ 16.  The axes' own
-    // 32 / 64 bytes go on the base pointers, which are scalars)
-    uint32_t ax, ay, az, bx, by, bz;  // a: offset of the bounds met first, b: of those met last
-    asm volatile("v_bfe_u32 %0, %2, 31, 1\n\tv_lshl_or_b32 %0, %0, 4, %3\n\tv_xor_b32 %1, 16, %0" : "=&v"(ax), "=&v"(bx) : "v"(r.inv.x), "v"(base));
-    asm volatile("v_bfe_u32 %0, %2, 31, 1\n\tv_lshl_or_b32 %0, %0, 4, %3\n\tv_xor_b32 %1, 16, %0" : "=&v"(ay), "=&v"(by) : "v"(r.inv.y), "v"(base));
-    asm volatile("v_bfe_u32 %0, %2, 31, 1\n\tv_lshl_or_b32 %0, %0, 4, %3\n\tv_xor_b32 %1, 16, %0" : "=&v"(az), "=&v"(bz) : "v"(r.inv.z), "v"(base));
-    float4 nx, fx, ny, fy, nz, fz, q6, q7;
+    const uint32_t base = cur * 64u;
+    uint4v g0, g1, g2, g3;
     if (LDS_TOP && cur < src.n_top) {
         lds_bytes* n = (lds_bytes*)src.top;
-        nx = f4(*(const lds_float4v*)(n + ax)); fx = f4(*(const lds_float4v*)(n + bx));
-        ny = f4(*(const lds_float4v*)(n + 32 + ay)); fy = f4(*(const lds_float4v*)(n + 32 + by));
-        nz = f4(*(const lds_float4v*)(n + 64 + az)); fz = f4(*(const lds_float4v*)(n + 64 + bz));
-        q6 = f4(*(const lds_float4v*)(n + (base + 96u))); q7 = f4(*(const lds_float4v*)(n + (base + 112u)));
+        g0 = *(const lds_uint4v*)(n + base); g1 = *(const lds_uint4v*)(n + (base + 16u));
+        g2 = *(const lds_uint4v*)(n + (base + 32u)); g3 = *(const lds_uint4v*)(n + (base + 48u));
     } else {
         const char* n = (const char*)src.nodes;
-        const char* n_y = n + 32;
-        const char* n_z = n + 64;
-        nx = *(const float4*)(n + ax); fx = *(const float4*)(n + bx);
-        ny = *(const float4*)(n_y + ay); fy = *(const float4*)(n_y + by);
-        nz = *(const float4*)(n_z + az); fz = *(const float4*)(n_z + bz);
-        q6 = *(const float4*)(n + (base + 96u)); q7 = *(const float4*)(n + (base + 112u));
+        g0 = *(const uint4v*)(n + base); g1 = *(const uint4v*)(n + (base + 16u));
+        g2 = *(const uint4v*)(n + (base + 32u)); g3 = *(const uint4v*)(n + (base + 48u));
     }
-    const float2v oxy = {r.o.x, r.o.y}, ixy = {r.inv.x, r.inv.y}, zz = {r.o.z, r.inv.z};
+    // per axis: A = (lo - o) / d, S = step / d; x and y travel as pairs, z as (S, A)
+    const float2v Axy = {(__uint_as_float(g0.x) - r.o.x) * r.inv.x, (__uint_as_float(g0.y) - r.o.y) * r.inv.y};
+    const float2v Sxy = {__uint_as_float(g0.w) * r.inv.x, __uint_as_float(g1.x) * r.inv.y};
+    const float2v SAz = {__uint_as_float(g1.y) * r.inv.z, (__uint_as_float(g0.z) - r.o.z) * r.inv.z};
+    // the words of the sides met first / last: (lower, upper) as stored where the direction is positive, swapped where not
+    const uint32_t sx = (uint32_t)((int32_t)__float_as_uint(r.inv.x) >> 31), sy = (uint32_t)((int32_t)__float_as_uint(r.inv.y) >> 31),
+                   sz = (uint32_t)((int32_t)__float_as_uint(r.inv.z) >> 31);
     // entry (tn) and exit (tf) distance of child k along each axis
     float tn[3][4], tf[3][4];
-    {
-        const float2v a0 = pk_mul_half<0>(pk_sub_half<0>(float2v{nx.x, nx.y}, oxy), ixy), a1 = pk_mul_half<0>(pk_sub_half<0>(float2v{nx.z, nx.w}, oxy), ixy);
-        const float2v b0 = pk_mul_half<0>(pk_sub_half<0>(float2v{fx.x, fx.y}, oxy), ixy), b1 = pk_mul_half<0>(pk_sub_half<0>(float2v{fx.z, fx.w}, oxy), ixy);
-        tn[0][0] = a0.x; tn[0][1] = a0.y; tn[0][2] = a1.x; tn[0][3] = a1.y;
-        tf[0][0] = b0.x; tf[0][1] = b0.y; tf[0][2] = b1.x; tf[0][3] = b1.y;
+#define RT_NODE_AXIS(AXIS, SIGN, LOWER, UPPER, SB, SC, BV, CV)                                                                        \
+    {                                                                                                                                 \
+        const uint32_t nw = ((UPPER) & (SIGN)) | ((LOWER) & ~(SIGN)), fw = ((LOWER) & (SIGN)) | ((UPPER) & ~(SIGN)); /* v_bfi_b32 */   \
+        const float2v n01 = {(float)(nw & 255u), (float)((nw >> 8) & 255u)}, n23 = {(float)((nw >> 16) & 255u), (float)(nw >> 24)};   \
+        const float2v f01 = {(float)(fw & 255u), (float)((fw >> 8) & 255u)}, f23 = {(float)((fw >> 16) & 255u), (float)(fw >> 24)};   \
+        const float2v a0 = pk_fma_half<SB, SC>(n01, BV, CV), a1 = pk_fma_half<SB, SC>(n23, BV, CV);                                   \
+        const float2v b0 = pk_fma_half<SB, SC>(f01, BV, CV), b1 = pk_fma_half<SB, SC>(f23, BV, CV);                                   \
+        tn[AXIS][0] = a0.x; tn[AXIS][1] = a0.y; tn[AXIS][2] = a1.x; tn[AXIS][3] = a1.y;                                               \
+        tf[AXIS][0] = b0.x; tf[AXIS][1] = b0.y; tf[AXIS][2] = b1.x; tf[AXIS][3] = b1.y;                                               \
     }
-    {
-        const float2v a0 = pk_mul_half<1>(pk_sub_half<1>(float2v{ny.x, ny.y}, oxy), ixy), a1 = pk_mul_half<1>(pk_sub_half<1>(float2v{ny.z, ny.w}, oxy), ixy);
-        const float2v b0 = pk_mul_half<1>(pk_sub_half<1>(float2v{fy.x, fy.y}, oxy), ixy), b1 = pk_mul_half<1>(pk_sub_half<1>(float2v{fy.z, fy.w}, oxy), ixy);
-        tn[1][0] = a0.x; tn[1][1] = a0.y; tn[1][2] = a1.x; tn[1][3] = a1.y;
-        tf[1][0] = b0.x; tf[1][1] = b0.y; tf[1][2] = b1.x; tf[1][3] = b1.y;
-    }
-    {
-        const float2v a0 = pk_mul_half<1>(pk_sub_half<0>(float2v{nz.x, nz.y}, zz), zz), a1 = pk_mul_half<1>(pk_sub_half<0>(float2v{nz.z, nz.w}, zz), zz);
-        const float2v b0 = pk_mul_half<1>(pk_sub_half<0>(float2v{fz.x, fz.y}, zz), zz), b1 = pk_mul_half<1>(pk_sub_half<0>(float2v{fz.z, fz.w}, zz), zz);
-        tn[2][0] = a0.x; tn[2][1] = a0.y; tn[2][2] = a1.x; tn[2][3] = a1.y;
-        tf[2][0] = b0.x; tf[2][1] = b0.y; tf[2][2] = b1.x; tf[2][3] = b1.y;
-    }
-    if (odd) {  // NaNs (0 * inf) drop out of fminf/fmaxf, as they do out of simd_min/simd_max in the reference
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float lo = fminf(tn[a][k], tf[a][k]), hi = fmaxf(tn[a][k], tf[a][k]);
-                tn[a][k] = lo;
-                tf[a][k] = hi;
-            }
-    }
-    // max / min over the axes and the ray's interval, NaNs dropping out as above: the instructions fmaxf / fminf compile to,
-    // spelled out so that none is spent on quieting operands that are results of arithmetic
-    float t_in[4];
-    float2v t_out[2];  // children 0, 1 | 2, 3: pairs, so that the slack factors multiply them two at a time
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float a, b, c;
-        if (Stack::ANY_INTERVAL) asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(tn[2][k]), "v"(r.tmin));
-        else asm("v_max_f32 %0, 0x3a83126f, %1" : "=v"(a) : "v"(tn[2][k]));  // RENDER_TMIN as a literal: no register holds it
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t_in[k]) : "v"(tn[0][k]), "v"(tn[1][k]), "v"(a));
-        asm("v_min_f32 %0, %1, %2" : "=v"(b) : "v"(tf[2][k]), "v"(tmax));
-        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(c) : "v"(tf[0][k]), "v"(tf[1][k]), "v"(b));
-        if (k & 1) t_out[k / 2].y = c;
-        else t_out[k / 2].x = c;
-    }
-    const uint32_t refs[4] = {__float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w)};
-    float2v slack[2] = {{q7.x, q7.y}, {q7.z, q7.w}};
+    RT_NODE_AXIS(0, sx, g1.z, g1.w, 0, 0, Sxy, Axy)
+    RT_NODE_AXIS(1, sy, g2.x, g2.y, 1, 1, Sxy, Axy)
+    RT_NODE_AXIS(2, sz, g2.z, g2.w, 0, 1, SAz, SAz)
+#undef RT_NODE_AXIS
+    // max / min over the axes and the ray's interval, NaNs dropping out: the instructions fmaxf / fminf compile to,
+    // spelled out (in one piece: the compiler pads every separate piece of assembly with idle cycles against hazards it
+    // cannot rule out) so that none is spent on quieting operands that are results of arithmetic
+    float t_in[4], t_out[4];
     if (Stack::ANY_INTERVAL) {
-        // a negative exit distance (only a caller's interval reaches below zero) is widened towards zero: 2 - slack = 1 - 2 ulp
-        if (t_out[0].x < 0.0f) slack[0].x = 2.0f - slack[0].x;
-        if (t_out[0].y < 0.0f) slack[0].y = 2.0f - slack[0].y;
-        if (t_out[1].x < 0.0f) slack[1].x = 2.0f - slack[1].x;
-        if (t_out[1].y < 0.0f) slack[1].y = 2.0f - slack[1].y;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a, b;
+            asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(tn[2][k]), "v"(r.tmin));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t_in[k]) : "v"(tn[0][k]), "v"(tn[1][k]), "v"(a));
+            asm("v_min_f32 %0, %1, %2" : "=v"(b) : "v"(tf[2][k]), "v"(tmax));
+            asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t_out[k]) : "v"(tf[0][k]), "v"(tf[1][k]), "v"(b));
+        }
+    } else {
+        // RENDER_TMIN as a literal: no register holds it
+        asm("v_max_f32 %0, 0x3a83126f, %8\n\tv_max_f32 %1, 0x3a83126f, %9\n\tv_max_f32 %2, 0x3a83126f, %10\n\tv_max_f32 %3, 0x3a83126f, %11\n\t"
+            "v_min_f32 %4, %12, %16\n\tv_min_f32 %5, %13, %16\n\tv_min_f32 %6, %14, %16\n\tv_min_f32 %7, %15, %16"
+            : "=&v"(t_in[0]), "=&v"(t_in[1]), "=&v"(t_in[2]), "=&v"(t_in[3]), "=&v"(t_out[0]), "=&v"(t_out[1]), "=&v"(t_out[2]), "=&v"(t_out[3])
+            : "v"(tn[2][0]), "v"(tn[2][1]), "v"(tn[2][2]), "v"(tn[2][3]), "v"(tf[2][0]), "v"(tf[2][1]), "v"(tf[2][2]), "v"(tf[2][3]), "v"(tmax));
+        asm("v_max3_f32 %0, %8, %12, %0\n\tv_max3_f32 %1, %9, %13, %1\n\tv_max3_f32 %2, %10, %14, %2\n\tv_max3_f32 %3, %11, %15, %3\n\t"
+            "v_min3_f32 %4, %16, %20, %4\n\tv_min3_f32 %5, %17, %21, %5\n\tv_min3_f32 %6, %18, %22, %6\n\tv_min3_f32 %7, %19, %23, %7"
+            : "+v"(t_in[0]), "+v"(t_in[1]), "+v"(t_in[2]), "+v"(t_in[3]), "+v"(t_out[0]), "+v"(t_out[1]), "+v"(t_out[2]), "+v"(t_out[3])
+            : "v"(tn[0][0]), "v"(tn[0][1]), "v"(tn[0][2]), "v"(tn[0][3]), "v"(tn[1][0]), "v"(tn[1][1]), "v"(tn[1][2]), "v"(tn[1][3]),
+              "v"(tf[0][0]), "v"(tf[0][1]), "v"(tf[0][2]), "v"(tf[0][3]), "v"(tf[1][0]), "v"(tf[1][1]), "v"(tf[1][2]), "v"(tf[1][3]));
     }
-    const float2v wide01 = t_out[0] * slack[0], wide23 = t_out[1] * slack[1];
-    const float t_wide[4] = {wide01.x, wide01.y, wide23.x, wide23.y};
+    const uint32_t refs[4] = {g3.x, g3.y, g3.z, g3.w};
     uint32_t key[4], ref[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        key[k] = t_in[k] <= t_wide[k] ? __float_as_uint(t_in[k]) : 0xFFFFFFFFu;  // slack NaN: empty slot, never entered
+        if (Stack::ANY_INTERVAL) {
+            // a caller's interval may reach below zero: a negative distance moves towards zero by 2^-18 of its own size where
+            // a positive entry distance is shrunk (for positive distances: the decisions and keys of the render path)
+            const float in = t_in[k] * (t_in[k] < 0.0f ? 2.0f - NODE_TEST_SHRINK : NODE_TEST_SHRINK);
+            const float out = t_out[k] < 0.0f ? t_out[k] * NODE_TEST_SHRINK : t_out[k];
+            key[k] = in <= out ? __float_as_uint(in) : 0xFFFFFFFFu;
+        } else {
+            // The entry distance shrunk by 2^-18 of itself is the key (a render's rays start at RENDER_TMIN: it is positive);
+            // the sign of exit - entry, spread over the word, turns it into the key of a missed child.  inf - inf (a child
+            // whose entry distance is infinite holds no hit either way) may fall on either side.
+            const float in = t_in[k] * NODE_TEST_SHRINK;
+            key[k] = __float_as_uint(in) | (uint32_t)((int32_t)__float_as_uint(t_out[k] - in) >> 31);
+        }
         ref[k] = refs[k];
     }
     order2(key[0], ref[0], key[1], ref[1]);
@@ -623,7 +643,7 @@ RT_D uint32_t leaf_step(const DScene& sc, const TravRay& r, uint32_t cur, float&
     float t;
     bool hit;
     if (ref_kind(cur) == KIND_MEDIUM) hit = medium_root<COUNT, GENERIC>(sc, ref_index(cur), r.o, r.d, r.time, r.a, r.tmin, tmax, key, t, pr);
-    else hit = leaf_root<COUNT>(sc, cur, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr);
+    else hit = leaf_root<COUNT, true>(sc, cur, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr, r.inv);
     if (hit) {
         tmax = t;
         best = cur;
@@ -1239,13 +1259,13 @@ __global__ __launch_bounds__(256) void k_primary_rays(DCamera cam, uint64_t seed
 #endif
 static constexpr int EXTEND_BLOCK = RT_EXTEND_BLOCK;
 
-// LDS of one block: 24 KiB, spent either on 12 stack levels per lane, or - for a tree small
+// LDS of one block: 22 KiB (seven blocks to a CU), spent either on 11 stack levels per lane, or - for a tree small
 // enough to be copied into LDS whole - on 8 stack levels and the tree (a copy of only the top
 // levels of a larger tree does not pay: those nodes are served by the L1 cache anyway, and
 // more LDS per block means fewer resident waves).
-static constexpr int SMALL_TREE_NODES = 128 / (RT_BVH_WIDTH / 2);  // 8 KiB of nodes
+static constexpr int SMALL_TREE_NODES = 96;  // 6 KiB of nodes
 #ifndef RT_EXTEND_STACK
-#define RT_EXTEND_STACK 12  // stack levels per lane kept in LDS (large trees)
+#define RT_EXTEND_STACK 11  // stack levels per lane kept in LDS (large trees): 22 KiB per block, seven blocks per CU
 #endif
 template <bool SMALL_TREE> struct ExtendLds {
     static constexpr int STACK_LEVELS = SMALL_TREE ? 8 : RT_EXTEND_STACK;
@@ -1254,10 +1274,10 @@ template <bool SMALL_TREE> struct ExtendLds {
 static constexpr int MIN_LDS_STACK = 8;
 static constexpr int OVERFLOW_STACK = STACK_SIZE - MIN_LDS_STACK;
 #ifndef RT_EXTEND_WAVES
-#define RT_EXTEND_WAVES 6  // resident waves per SIMD the register allocation aims for
+#define RT_EXTEND_WAVES 7  // resident waves per SIMD the register allocation aims for (72 registers)
 #endif
 template <bool COUNT, bool SMALL_TREE, bool GENERIC, bool OVERFLOW = true>
-__global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GENERIC ? RT_EXTEND_WAVES - 1 : RT_EXTEND_WAVES, GENERIC ? RT_EXTEND_WAVES - 1 : RT_EXTEND_WAVES))) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
+__global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GENERIC ? 5 : RT_EXTEND_WAVES, GENERIC ? 5 : RT_EXTEND_WAVES))) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                          const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
                                                          const float4* __restrict__ ray_d, uint2* __restrict__ hits,
                                                          unsigned long long* __restrict__ stack_overflow, ExtendTuning tune,
@@ -1410,7 +1430,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             if (__ballot(at_prim)) moved = true;
             if (at_prim) {
                 float t;
-                if (leaf_root<COUNT>(sc, cur, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr)) { tmax = t; best = cur; }
+                if (leaf_root<COUNT, true>(sc, cur, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr, r.inv)) { tmax = t; best = cur; }
                 cur = pop_next(st, tmax);
             }
         }

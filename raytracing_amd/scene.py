@@ -374,6 +374,19 @@ class Scene(BuilderCalls):
         """First bounce the tail kernel takes over (-1: chosen per batch; >= max_depth: never)."""
         self._check(self.amd.rt_ctx_set_tail_start(self.ctx, first_bounce))
 
+    def set_host_buffer_pinning(self, on):
+        """Opt in to rt_render_accumulate keeping the caller's buffer registered (see include/rt_abi.h: release it before freeing)."""
+        self._check(self.amd.rt_ctx_set_host_buffer_pinning(self.ctx, int(on)))
+
+    def release_host_buffer(self):
+        self._check(self.amd.rt_ctx_release_host_buffer(self.ctx))
+
+    def memory_info(self):
+        """(free, total) device memory in bytes on this scene's GPU."""
+        free, total = C.c_size_t(), C.c_size_t()
+        self._check(self.amd.rt_ctx_memory_info(self.ctx, C.byref(free), C.byref(total)))
+        return int(free.value), int(total.value)
+
     def set_counters(self, on):
         self._check(self.amd.rt_ctx_set_counters(self.ctx, int(on)))
 
