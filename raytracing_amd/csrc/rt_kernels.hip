@@ -94,6 +94,7 @@ RT_D void quad_alpha_beta(float4 qq, float4 uu, float4 vv, float3 p, float& alph
 // own_box (may be NULL): the quad's own AABB, min and max; a hit then only counts if own_box_test passes for it (see
 // leaf_root).  inv = 1 / d, used by that test only.
 RT_D bool own_box_test(float4 mn, float4 mx, float3 o, float3 inv, float lo, float hi);
+RT_D bool own_box_test_of_walk(float4 mn, float4 mx, float3 o, float3 d, float3 inv, float lo, float hi);
 RT_D bool quad_root(const float4* __restrict__ q4, float4 nd, float3 o, float3 d, float tmin, float tmax, float& t,
                     const float4* __restrict__ own_box = nullptr, float3 inv = make_float3(0.0f, 0.0f, 0.0f)) {
     float3 N = f3(nd);
@@ -110,7 +111,7 @@ RT_D bool quad_root(const float4* __restrict__ q4, float4 nd, float3 o, float3 d
     if (!(0.0f <= alpha && alpha <= 1.0f)) return false;
     const float beta = dot3(w, cross3(f3(uu), h));
     if (!(0.0f <= beta && beta <= 1.0f)) return false;
-    if (own_box && !own_box_test(mn, mx, o, inv, tmin, tmax)) return false;
+    if (own_box && !own_box_test_of_walk(mn, mx, o, d, inv, tmin, tmax)) return false;
     t = tt;
     return true;
 }
@@ -202,7 +203,7 @@ RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float ti
             ray_to_object(xf[0], xf[1], o, d);
             a = dot3(d, d);
         }
-        return sphere_root(c, s.w, o, d, a, tmin, tmax, t) && (!own_box || own_box_test(mn, mx, o, inv, tmin, tmax));
+        return sphere_root(c, s.w, o, d, a, tmin, tmax, t) && (!own_box || own_box_test_of_walk(mn, mx, o, d, inv, tmin, tmax));
     } else {
         if (COUNT) pr.quads++;
         const float4* q4 = sc.quads + 4 * (size_t)idx;
@@ -221,6 +222,13 @@ RT_D bool own_box_test(float4 mn, float4 mx, float3 o, float3 inv, float lo, flo
     const float t_in = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), fminf(lo, hi)));
     const float t_out = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), fmaxf(lo, hi)));
     return t_in <= t_out;
+}
+
+// The same with the tree walk's 1 / d (TravRay::inv), which differs from 1 / d only where it has been limited: the few rays
+// that concerns take the divisions again.
+RT_D bool own_box_test_of_walk(float4 mn, float4 mx, float3 o, float3 d, float3 inv, float lo, float hi) {
+    if (fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z)) >= 0x1p100f) inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    return own_box_test(mn, mx, o, inv, lo, hi);
 }
 
 // Closest hit of a medium's boundary object inside (lo, hi): one of the two nested queries of ConstantMediumPhase1/2
@@ -420,18 +428,24 @@ struct WaveStack {
 static constexpr float RENDER_TMIN = 0.001f;
 static_assert(__builtin_bit_cast(uint32_t, RENDER_TMIN) == 0x3a83126fu, "node_step spells this constant out in an instruction");
 struct TravRay {
-    float3 o, d, inv;
+    float3 o, d;
+    float3 inv;  // 1 / d, limited to +-INV_LIMIT
     float time, a, tmin;
-    bool odd;  // some component of the origin or of 1 / direction is not finite, or 1 / direction is zero: see node_step
 };
 
+// The walk's 1 / direction stays finite.  With an infinite one (a direction component that is zero: the middle row of an
+// image whose camera looks along an axis plane has such rays) the grid form of the slab distances, q * (step / d) +
+// (lo - o) / d, is inf - inf or 0 * inf for every child: the axis would drop out of the test, and the ray would visit
+// every box along its line whatever their position on that axis.  With the limit, the distances of that axis are huge and of
+// the right sign: beyond any tmax where the origin is outside the slab, on either side of the ray's interval where it is
+// inside.  A component smaller than 2^-100 is treated as if it were larger: that only lets more children pass.
+static constexpr float INV_LIMIT = 0x1p100f;
 RT_D TravRay make_trav_ray(float3 o, float3 d, float time, float tmin) {
     TravRay r;
     r.o = o; r.d = d; r.time = time; r.tmin = tmin;
     r.a = dot3(d, d);
-    r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    auto plain = [](float inv, float o) { return fabsf(inv) > 0.0f && fabsf(inv) < RT_INF && fabsf(o) < RT_INF; };
-    r.odd = !(plain(r.inv.x, o.x) && plain(r.inv.y, o.y) && plain(r.inv.z, o.z));
+    r.inv = f3(__builtin_amdgcn_fmed3f(1.0f / d.x, -INV_LIMIT, INV_LIMIT), __builtin_amdgcn_fmed3f(1.0f / d.y, -INV_LIMIT, INV_LIMIT),
+               __builtin_amdgcn_fmed3f(1.0f / d.z, -INV_LIMIT, INV_LIMIT));
     return r;
 }
 
@@ -470,7 +484,7 @@ static constexpr uint32_t NODE_FLOAT4S = 4;  // 64 bytes per node, whichever the
 // slack 1, so the same leaves get tested as in the reference.
 #if RT_BVH_WIDTH == 2
 template <bool COUNT, bool LDS_TOP, class Stack>
-RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr, bool /*odd*/) {
+RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr) {
     if (COUNT) pr.nodes++;
     float4 n0, n1, n2, n3;
     if (LDS_TOP && cur < src.n_top) {
@@ -516,9 +530,9 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
 // node's extent (pack_nodes), against roundings here of a few 2^-24 of that extent, and the entry distance is shrunk by
 // 2^-18 of itself, against roundings of a few 2^-24 of the distances.  It decides which children are looked at.  What
 // is hit is decided by the leaves' own tests, and for a leaf that sits in world space by the reference's test of the
-// leaf's own box on top (leaf_box_passes below), as in the reference's tree.  NaN distances (0 * inf for a direction
-// component that is zero) drop out of the max / min reductions, as they do out of simd_min / simd_max in the reference,
-// and so never cull a child.
+// leaf's own box on top (own_box_test_of_walk), as in the reference's tree.  1 / d is finite here (make_trav_ray), so a
+// NaN distance takes a NaN or infinite origin, or an infinite coordinate; it drops out of the max / min reductions, as it
+// does out of simd_min / simd_max in the reference, and so never culls a child.
 // The children that are hit are ordered by entry distance with a five-exchange sorting network (entry distances
 // are positive, so their bit patterns order like the numbers; a child that is missed gets the
 // key ~0), the nearest is continued with and the others are stacked farthest first.
@@ -543,7 +557,7 @@ RT_D float2v pk_fma_half(float2v a, float2v b, float2v c) {
 }
 static constexpr float NODE_TEST_SHRINK = 1.0f - 0x1p-18f;   // what the entry distance of a child's grid box is multiplied by
 template <bool COUNT, bool LDS_TOP, class Stack>
-RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr, bool odd) {
+RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, float tmax, Stack& st, Probe& pr) {
     if (COUNT) pr.nodes++;
     const uint32_t base = cur * 64u;
     uint4v g0, g1, g2, g3;
@@ -749,9 +763,8 @@ template <bool COUNT, bool GENERIC, class Stack, class Key>
 RT_D void walk_tree(const DScene& sc, const TravRay& r, float& tmax, uint32_t& best, const Key& key, Stack& st, Probe& pr) {
     const NodeSource src{sc.nodes, nullptr, 0};
     uint32_t cur = sc.root == REF_NONE ? REF_DONE : sc.root;
-    const bool odd = __ballot(r.odd) != 0;  // the same for the whole wave
     while (cur != REF_DONE) {
-        if (!ref_is_leaf(cur)) cur = node_step<COUNT, false>(src, r, cur, tmax, st, pr, odd);
+        if (!ref_is_leaf(cur)) cur = node_step<COUNT, false>(src, r, cur, tmax, st, pr);
         else cur = leaf_step<COUNT, GENERIC>(sc, r, cur, tmax, best, key, st, pr);
     }
 }
@@ -1341,16 +1354,22 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
     const uint32_t root = sc.root == REF_NONE ? REF_DONE : sc.root;
     const bool first_leaves_done = sc.n_global != 0;  // k_first_leaves has run: hits[] holds each ray's starting (tmax, leaf)
 
-    bool odd = false;  // some ray this wave has fetched needs node_step's min / max; stays on to the end of the launch
-
     // A turn in which no part ran (the thresholds below held every lane back) is followed by one
     // that runs every part for whatever lanes it has, so the loop always moves on.
     bool eager = false;
+#ifdef RT_WAVE_TIMES  // development aid: prints the life span and the node-loop turns of every 16th wave
+    const unsigned long long t_start = wall_clock64();
+    uint32_t node_turns = 0, overflow_turns = 0, my_visits = 0;
+#endif
     for (;;) {
         bool moved = false;
         const int refill_min = eager ? 1 : tune.refill_min, inner_min = eager ? 1 : tune.inner_min, medium_min = eager ? 1 : tune.medium_min;
         if (__ballot(cur == REF_DONE)) moved = true;
         if (cur == REF_DONE) {  // retire
+#ifdef RT_WAVE_TIMES
+            if (my_visits > 3000) printf("ray %u visits %u o %.9g %.9g %.9g d %.9g %.9g %.9g t %g best %x\n", mine, my_visits, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, tmax, best);
+            my_visits = 0;
+#endif
             hits[mine] = make_uint2(__float_as_uint(tmax), best);
             if (COUNT) { segs++; nhit += (best != REF_NONE); }
             cur = REF_NONE;
@@ -1376,7 +1395,6 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
 #endif
             uint32_t rank = (uint32_t)__popcll(m_idle & ((1ull << lane) - 1ull));
             const bool fetch = cur == REF_NONE && rank < avail;
-            bool odd_ray = false;
             if (fetch) {
                 mine = next + rank;
                 // the ray and its starting hit record in one round trip: all three loads go out before anything waits
@@ -1390,9 +1408,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
                 best = h0.y;
                 st.sp = 0;
                 cur = root;
-                odd_ray = r.odd;
             }
-            if (__ballot(odd_ray) != 0) odd = true;
             next += n_refill;
         }
         // inner nodes
@@ -1411,7 +1427,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             if (COUNT) slots++;
 #endif
             if (at_inner) {
-                cur = node_step<COUNT, SMALL_TREE>(src, r, cur, tmax, st, pr, odd);
+                cur = node_step<COUNT, SMALL_TREE>(src, r, cur, tmax, st, pr);
                 if (COUNT) pr.max_sp = max(pr.max_sp, (uint32_t)st.sp);
 #if RT_LANE_STATS == 7
                 if (COUNT && st.sp > LDS_STACK) slots++;  // node steps that leave the lane's stack in the global part
@@ -1419,6 +1435,11 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             }
 #if RT_LANE_STATS == 8
             if (COUNT && __ballot(at_inner && st.sp > LDS_STACK)) slots++;  // turns of the node loop with some lane's stack in the global part
+#endif
+#ifdef RT_WAVE_TIMES
+            if (at_inner) my_visits++;
+            node_turns++;
+            if (__ballot(at_inner && st.sp > LDS_STACK)) overflow_turns++;
 #endif
         }
         // sphere and quad leaves
@@ -1460,6 +1481,9 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
         }
         eager = !moved;
     }
+#ifdef RT_WAVE_TIMES
+    if (lane == 0 && ((wave & 255u) == 0 || node_turns > RT_WAVE_TIMES)) printf("wave %u %u start %llu end %llu turns %u overflow %u\n", bounce, wave, t_start, wall_clock64(), node_turns, overflow_turns);
+#endif
     if (COUNT) flush_probe(counters, pr, segs, nhit, slots);
 }
 
