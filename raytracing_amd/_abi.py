@@ -165,6 +165,7 @@ RTH_API = {
     "rth_empty_render": (C.c_int, [_P]),
     "rth_hdr_render": (C.c_int, [_P, _P]),
     "rth_realtime_render": (C.c_int, [_P, _P]),
+    "rth_realtime_render_view": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "rth_download_accumulator": (C.c_int, [_P, _P]),
     "rth_render_to_image": (C.c_int, [_P, _U64, C.c_char_p, _P]),
     "rth_save_checkpoint": (C.c_int, [_P, C.c_char_p]),

@@ -172,8 +172,16 @@ int rth_hdr_render(void* p, float* out_rgb) {
 }
 int rth_realtime_render(void* p, uint32_t* out) {
     return guard([&] {
-        const std::vector<uint32_t>& img = cam(p)->realtime_render();
+        const Camera::Words img = cam(p)->realtime_render();
         std::memcpy(out, img.data(), img.size() * sizeof(uint32_t));
+    });
+}
+// The same without the copy: *words points into the camera's own (page-locked) frame, valid until its next render call.
+int rth_realtime_render_view(void* p, const uint32_t** words, uint64_t* n_words) {
+    return guard([&] {
+        const Camera::Words img = cam(p)->realtime_render();
+        *words = img.data();
+        *n_words = img.size();
     });
 }
 int rth_download_accumulator(void* p, float* out) {

@@ -381,7 +381,6 @@ Camera::Camera(Arena& arena, Vec3 position, Vec3 direction, std::pair<size_t, si
       focus_dist_(focus_dist), defocus_angle_(defocus_angle), max_depth_(max_depth), background_colour_(background_colour) {
     rt_cam_ = raytracing_camera(resolution.first, resolution.second, max_depth, vfov, position, position + direction, vup, defocus_angle,
                                 focus_dist, background_colour);
-    final_colours_.assign(resolution.first * resolution.second, 0u);
     device_ = device;
     // the reference starts with a unit sphere of the default material (:53-56)
     set_world(World::make(arena.alloc_new(Hittable::sphere(Sphere::make(Point::ZERO(), 1.0f, MaterialId{}))), MaterialMap()));
@@ -396,6 +395,8 @@ void Camera::ensure_backend() {
         check(rt_buffer_create(ctx_, n * 4 * sizeof(float), (void**)&d_acc_), "rt_buffer_create");
         check(rt_buffer_create(ctx_, n * 4 * sizeof(float), &d_out_), "rt_buffer_create");
         check(rt_buffer_zero(ctx_, d_acc_, n * 4 * sizeof(float)), "rt_buffer_zero");
+        check(rt_host_buffer_create(ctx_, n * sizeof(uint32_t), (void**)&final_colours_), "rt_host_buffer_create");
+        std::memset(final_colours_, 0, n * sizeof(uint32_t));
     }
     if (scene_dirty_) {
         rt_scene_desc d = flat_.desc();
@@ -412,6 +413,7 @@ Camera::~Camera() {
     if (ctx_) {
         rt_buffer_destroy(ctx_, d_acc_);
         rt_buffer_destroy(ctx_, d_out_);
+        rt_host_buffer_destroy(ctx_, final_colours_);
         rt_ctx_destroy(ctx_);
     }
 }
@@ -457,12 +459,12 @@ void Camera::render_samples(uint32_t n) {
 
 void Camera::empty_render() { render_samples(1); }  // :80-85
 
-const std::vector<uint32_t>& Camera::realtime_render() {  // :89-104
+Camera::Words Camera::realtime_render() {  // :89-104
     render_samples(1);
     size_t n = render_resolution_.first * render_resolution_.second;
     check(rt_finalize_device(ctx_, d_acc_, n, (uint32_t)samples_, RT_FINALIZE_TONEMAP_RGBA, exposure_, d_out_), "rt_finalize_device");
-    check(rt_buffer_download(ctx_, final_colours_.data(), d_out_, n * sizeof(uint32_t)), "rt_buffer_download");
-    return final_colours_;
+    check(rt_buffer_download(ctx_, final_colours_, d_out_, n * sizeof(uint32_t)), "rt_buffer_download");
+    return Words{final_colours_, n};
 }
 
 std::vector<Vec3> Camera::hdr_render() {  // :107-122

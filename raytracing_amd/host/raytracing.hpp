@@ -222,7 +222,18 @@ class Camera {
     void set_exposure(float exposure);
     void set_world(World world);
     void empty_render();                          // one more sample per pixel
-    const std::vector<uint32_t>& realtime_render();   // one more sample, tone-mapped 0BGR words
+    // One more sample, tone-mapped 0BGR words.  Like the reference's `&[u32]`, the words live in the camera (in page-locked
+    // memory, so that the download is one DMA transfer) and are valid until its next render call.
+    struct Words {
+        const uint32_t* ptr = nullptr;
+        size_t len = 0;
+        const uint32_t* data() const { return ptr; }
+        size_t size() const { return len; }
+        const uint32_t& operator[](size_t i) const { return ptr[i]; }
+        const uint32_t* begin() const { return ptr; }
+        const uint32_t* end() const { return ptr + len; }
+    };
+    Words realtime_render();
     std::vector<Vec3> hdr_render();               // one more sample, sqrt(mean)
     // Not in the reference: `n` consecutive empty_render calls in one GPU submission.
     void render_samples(uint32_t n);
@@ -272,7 +283,7 @@ class Camera {
     float focus_dist_, defocus_angle_;
     size_t max_depth_;
     rt_camera_desc rt_cam_{};
-    std::vector<uint32_t> final_colours_;
+    uint32_t* final_colours_ = nullptr;  // page-locked, one word per pixel (created with the backend)
     size_t samples_ = 0;
     World world_;
     Colour background_colour_;

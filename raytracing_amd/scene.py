@@ -188,11 +188,20 @@ class Scene(BuilderCalls):
         self._check_host(self.host.rth_hdr_render(self._h, out.ctypes.data))
         return out
 
-    def realtime_render(self):
+    def realtime_render(self, copy=True):
+        """One more sample per pixel, tone-mapped and packed (0BGR words, src/camera.rs:89-104).  copy=False returns a view
+        of the camera's own page-locked frame instead of a fresh array - what the reference's `&[u32]` is: valid until
+        this scene's next render call, and 0.1 - 0.2 ms per frame cheaper at 800x800."""
         w, h = self.resolution
-        out = np.empty((h, w), np.uint32)
-        self._check_host(self.host.rth_realtime_render(self._h, out.ctypes.data))
-        return out
+        if copy:
+            out = np.empty((h, w), np.uint32)
+            self._check_host(self.host.rth_realtime_render(self._h, out.ctypes.data))
+            return out
+        words, n = C.c_void_p(), C.c_uint64()
+        self._check_host(self.host.rth_realtime_render_view(self._h, C.byref(words), C.byref(n)))
+        frame = np.ctypeslib.as_array(C.cast(words, C.POINTER(C.c_uint32)), shape=(h, w))
+        frame.flags.writeable = False
+        return frame
 
     def accumulator(self):
         w, h = self.resolution

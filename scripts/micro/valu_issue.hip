@@ -102,6 +102,27 @@ ISSUE_KERNEL(k_fmac, "v_fmac_f32 %0, %3, %4")
 ISSUE_KERNEL(k_mad_u32_u24, "v_mad_u32_u24 %2, %2, %6, %6")
 ISSUE_KERNEL(k_sub_u32, "v_sub_u32 %2, %2, %6")
 ISSUE_KERNEL(k_lshrrev, "v_lshrrev_b32 %2, 1, %2")
+ISSUE_KERNEL(k_cndmask_e64_vcc, "v_cndmask_b32_e64 %0, %0, %3, vcc")
+ISSUE_KERNEL(k_cmp_cndmask_vcc, "v_cmp_lt_u32 vcc, %2, %6\n\tv_cndmask_b32 %0, %0, %3, vcc")
+ISSUE_KERNEL(k_cmp_cndmask_sgpr, "v_cmp_lt_u32 s[20:21], %2, %6\n\tv_cndmask_b32_e64 %0, %0, %3, s[20:21]")
+ISSUE_KERNEL(k_cmp_cndmask_e64_vcc, "v_cmp_lt_u32 vcc, %2, %6\n\tv_cndmask_b32_e64 %0, %0, %3, vcc")
+ISSUE_KERNEL(k_div_scale, "v_div_scale_f32 %0, vcc, %0, %3, %0")
+ISSUE_KERNEL(k_div_fmas, "v_div_fmas_f32 %0, %0, %3, %4")
+ISSUE_KERNEL(k_div_fixup, "v_div_fixup_f32 %0, %0, %3, %4")
+ISSUE_KERNEL(k_addc_vcc, "v_addc_co_u32 %2, vcc, %2, %6, vcc")
+ISSUE_KERNEL(k_addc_sgpr, "v_addc_co_u32_e64 %2, s[20:21], %2, %6, s[20:21]")
+ISSUE_KERNEL(k_add_co, "v_add_co_u32 %2, vcc, %2, %6")
+ISSUE_KERNEL(k_mad_u64_u32, "v_mad_u64_u32 %1, s[20:21], %2, %6, %1")
+ISSUE_KERNEL(k_cmp_class, "v_cmp_class_f32 vcc, %0, %6")
+ISSUE_KERNEL(k_readfirstlane, "v_readfirstlane_b32 s20, %0")
+ISSUE_KERNEL(k_log, "v_log_f32 %0, %0")
+ISSUE_KERNEL(k_exp, "v_exp_f32 %0, %0")
+ISSUE_KERNEL(k_rsq, "v_rsq_f32 %0, %0")
+ISSUE_KERNEL(k_mul_f64, "v_mul_f64 %1, %1, %1")
+ISSUE_KERNEL(k_lshl_b64, "v_lshlrev_b64 %1, 1, %1")
+ISSUE_KERNEL(k_bfi, "v_bfi_b32 %2, %6, %2, %6")
+ISSUE_KERNEL(k_alignbit, "v_alignbit_b32 %2, %2, %6, 5")
+ISSUE_KERNEL(k_med3, "v_med3_f32 %0, %0, %3, %4")
 ISSUE_KERNEL(k_mix, "v_fma_f32 %0, %0, %3, %4\n\tv_pk_mul_f32 %1, %1, %5\n\tv_min_u32 %2, %2, %6")
 
 typedef void (*kernel_t)(unsigned long long*, float*, float);
@@ -159,6 +180,10 @@ int main() {
     RUN(k_perm, 1); RUN(k_mov_dpp, 1); RUN(k_fma_mix, 1);
     RUN(k_cndmask_sgpr, 1); RUN(k_cndmask_nodep, 1); RUN(k_cndmask_imm, 1); RUN(k_sub, 1); RUN(k_ashr, 1); RUN(k_or, 1); RUN(k_and_or, 1);
     RUN(k_min_f32, 1); RUN(k_fmac, 1); RUN(k_mad_u32_u24, 1); RUN(k_sub_u32, 1); RUN(k_lshrrev, 1);
+    RUN(k_cndmask_e64_vcc, 1); RUN(k_cmp_cndmask_vcc, 2); RUN(k_cmp_cndmask_sgpr, 2); RUN(k_cmp_cndmask_e64_vcc, 2);
+    RUN(k_div_scale, 1); RUN(k_div_fmas, 1); RUN(k_div_fixup, 1); RUN(k_addc_vcc, 1); RUN(k_addc_sgpr, 1); RUN(k_add_co, 1); RUN(k_mad_u64_u32, 1);
+    RUN(k_cmp_class, 1); RUN(k_readfirstlane, 1); RUN(k_log, 1); RUN(k_exp, 1); RUN(k_rsq, 1); RUN(k_mul_f64, 1); RUN(k_lshl_b64, 1);
+    RUN(k_bfi, 1); RUN(k_alignbit, 1); RUN(k_med3, 1);
     RUN(k_mix, 3);
     return 0;
 }

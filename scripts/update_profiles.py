@@ -1,6 +1,6 @@
 """Copies what scripts/final_profiles.sh left under gpurun_out/ into profiles/ and rewrites profiles/traffic.json from the
 new PMC summary.  usage: python scripts/update_profiles.py <tag in gpurun_out, e.g. r02d> <prefix in profiles, e.g. r02_c>"""
-import glob, json, os, shutil, sys
+import datetime, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, dst = sys.argv[1], sys.argv[2]
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
@@ -26,6 +26,9 @@ t["extend_issue"].update({"source": f"{src} (SQ passes, one pipeline, 16 spp of 
                           "wait_share_of_wave_cycles": e["wait_any_share_of_wave_cycles"],
                           "valu_insts_per_segment_wave": round(e["raw"]["SQ_INSTS_VALU"] / (segments / 64), 1),
                           "whole_step_valu_issue_share": round(valu * 4 / (1024 * 2.4e9 * secs), 3)})
+# which code the numbers belong to: the commit the working tree was at when they were copied in, and the day
+t["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+t["date"] = datetime.date.today().isoformat()
 json.dump(t, open(f"{P}/traffic.json", "w"), indent=1)
 b = json.load(open(f"{P}/{dst}_bench.json"))
 print("bench", b["value"], "Msamples/s; extend", b["roofline"]["avg_launch_ms"], "ms per launch, alone", b["roofline"]["alone"]["avg_launch_ms"])

@@ -829,6 +829,12 @@ def test_camera_entry_points_and_finalize():
     ref = ob.finalize(s.accumulator(), 4, _abi.FINALIZE_TONEMAP_RGBA, exposure=1.0)
     diff = np.abs(((rgba[..., None] >> np.array([0, 8, 16])) & 0xFF).astype(int) - ((ref[..., None] >> np.array([0, 8, 16])) & 0xFF).astype(int))
     assert diff.max() <= 1 and (rgba >> 24 == 0).all()
+    # the frame without the copy: a read-only view of the camera's own words, here of the fifth sample's frame
+    view = s.realtime_render(copy=False)
+    assert s.samples == 5 and view.shape == rgba.shape and view.dtype == np.uint32 and not view.flags.writeable
+    ref5 = ob.finalize(s.accumulator(), 5, _abi.FINALIZE_TONEMAP_RGBA, exposure=1.0)
+    diff5 = np.abs(((view[..., None] >> np.array([0, 8, 16])) & 0xFF).astype(int) - ((ref5[..., None] >> np.array([0, 8, 16])) & 0xFF).astype(int))
+    assert diff5.max() <= 1 and (view >> 24 == 0).all() and not np.array_equal(view, rgba)
     assert np.array_equal(s.finalize(acc, 3, _abi.FINALIZE_MEAN), ob.finalize(acc, 3, _abi.FINALIZE_MEAN))
     s.change_pitch_yaw_by(1.0, 0.0)  # moving the camera restarts the accumulation (src/camera.rs:149-160)
     assert s.samples == 0
