@@ -380,14 +380,15 @@ struct PrivateStack {  // per-lane array (scratch memory): used by the record-ba
     uint32_t ref[STACK_SIZE];
     float t[STACK_SIZE];
     int sp = 0;
-    RT_D void push(uint32_t r, float tt) { ref[sp] = r; t[sp] = tt; ++sp; }
-    RT_D bool pop(uint32_t& r, float& tt) {
+    template <bool SHALLOW = false> RT_D void push(uint32_t r, float tt) { ref[sp] = r; t[sp] = tt; ++sp; }
+    template <bool SHALLOW = false> RT_D bool pop(uint32_t& r, float& tt) {
         if (sp == 0) return false;
         --sp;
         r = ref[sp];
         tt = t[sp];
         return true;
     }
+    RT_D bool wave_is_shallow(int) const { return false; }
 };
 
 // Stack of the render path's extend kernel.  An entry is 64 bits: (entry distance << 32) | ref.
@@ -405,22 +406,27 @@ struct WaveStack {
     global_u64* ovf;  // the wave's area (the same pointer in all its lanes, so it lives in scalar registers): level LEVELS + k of lane l at ovf[64 * k + l]
     uint32_t lane;
     int sp = 0;
-    RT_D void push(uint32_t r, float tt) {
+    // SHALLOW: the caller has checked (wave_is_shallow) that this access cannot reach the global part
+    template <bool SHALLOW = false> RT_D void push(uint32_t r, float tt) {
         unsigned long long e = ((unsigned long long)__float_as_uint(tt) << 32) | r;
-        if (!OVERFLOW || sp < LEVELS) lds[64 * sp] = e;
+        if (!OVERFLOW || SHALLOW || sp < LEVELS) lds[64 * sp] = e;
         else ovf[64u * (uint32_t)(sp - LEVELS) + lane] = e;
         ++sp;
     }
-    RT_D bool pop(uint32_t& r, float& tt) {
+    template <bool SHALLOW = false> RT_D bool pop(uint32_t& r, float& tt) {
         if (sp == 0) return false;
         --sp;
         unsigned long long e;
-        if (!OVERFLOW || sp < LEVELS) e = lds[64 * sp];
+        if (!OVERFLOW || SHALLOW || sp < LEVELS) e = lds[64 * sp];
         else e = ovf[64u * (uint32_t)(sp - LEVELS) + lane];
         r = (uint32_t)e;
         tt = __uint_as_float((uint32_t)(e >> 32));
         return true;
     }
+    // No lane of the wave is within `room` entries of the end of the LDS levels: up to `room` pushes, and any number of pops,
+    // stay in LDS for every lane.  One comparison per node for the wave, instead of one branch per push and pop and lane:
+    // the scalar instructions of those branches (exec-mask bookkeeping) are what the extend kernel's time is most sensitive to.
+    RT_D bool wave_is_shallow(int room) const { return !OVERFLOW || __ballot(sp > LEVELS - room) == 0ull; }
 };
 
 // Start of the interval of every ray of a render (src/camera.rs:346: Interval::new(0.001, f32::MAX)); rays that come with
@@ -451,11 +457,11 @@ RT_D TravRay make_trav_ray(float3 o, float3 d, float time, float tmin) {
 
 // Next reference to process after the current one is finished: pops until an entry that can
 // still hold a closer hit, REF_DONE when the stack runs out.
-template <class Stack>
+template <bool SHALLOW = false, class Stack>
 RT_D uint32_t pop_next(Stack& st, float tmax) {
     uint32_t r;
     float tt;
-    while (st.pop(r, tt))
+    while (st.template pop<SHALLOW>(r, tt))
         if (tt <= tmax) return r;
     return REF_DONE;
 }
@@ -618,6 +624,20 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
             : "v"(tn[0][0]), "v"(tn[0][1]), "v"(tn[0][2]), "v"(tn[0][3]), "v"(tn[1][0]), "v"(tn[1][1]), "v"(tn[1][2]), "v"(tn[1][3]),
               "v"(tf[0][0]), "v"(tf[0][1]), "v"(tf[0][2]), "v"(tf[0][3]), "v"(tf[1][0]), "v"(tf[1][1]), "v"(tf[1][2]), "v"(tf[1][3]));
     }
+#if defined(RT_EXTRA_NODE_VALU) || defined(RT_EXTRA_NODE_SALU)  // timing experiments (development builds): instructions that do nothing
+    {
+#ifdef RT_EXTRA_NODE_VALU
+        float sink = t_in[0];
+#pragma unroll
+        for (int x = 0; x < RT_EXTRA_NODE_VALU; ++x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(sink) : "v"(t_out[x & 3]));
+        asm volatile("" :: "v"(sink));
+#endif
+#ifdef RT_EXTRA_NODE_SALU
+#pragma unroll
+        for (int x = 0; x < RT_EXTRA_NODE_SALU; ++x) asm volatile("s_mov_b32 s50, 0" ::: "s50");
+#endif
+    }
+#endif
     const uint32_t refs[4] = {g3.x, g3.y, g3.z, g3.w};
     uint32_t key[4], ref[4];
 #pragma unroll
@@ -642,6 +662,13 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
     order2(key[0], ref[0], key[2], ref[2]);
     order2(key[1], ref[1], key[3], ref[3]);
     order2(key[1], ref[1], key[2], ref[2]);
+    if (st.wave_is_shallow(3)) {  // the usual case: neither the pushes nor the pops of this node can leave the LDS levels
+        if (key[0] == 0xFFFFFFFFu) return pop_next<true>(st, tmax);
+        if (key[3] != 0xFFFFFFFFu) st.template push<true>(ref[3], __uint_as_float(key[3]));
+        if (key[2] != 0xFFFFFFFFu) st.template push<true>(ref[2], __uint_as_float(key[2]));
+        if (key[1] != 0xFFFFFFFFu) st.template push<true>(ref[1], __uint_as_float(key[1]));
+        return ref[0];
+    }
     if (key[0] == 0xFFFFFFFFu) return pop_next(st, tmax);
     if (key[3] != 0xFFFFFFFFu) st.push(ref[3], __uint_as_float(key[3]));
     if (key[2] != 0xFFFFFFFFu) st.push(ref[2], __uint_as_float(key[2]));
@@ -1307,9 +1334,10 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
     __shared__ uint32_t s_cursor;  // 64-ray blocks the waves of this thread block have taken so far
     if (threadIdx.x == 0) s_cursor = 0;
     __syncthreads();
-    const uint32_t n = counts[bounce];
+    // (values that are the same in all lanes of a wave are said to be so explicitly: that keeps the queue bookkeeping and the
+    // loop's decisions below in scalar registers and scalar branches)
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)counts[bounce]);
     const uint32_t lane = threadIdx.x & 63;
-    // the same value in all lanes of a wave: said so explicitly, which keeps the queue bookkeeping below in scalar registers
     const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t wave = blockIdx.x * (EXTEND_BLOCK / 64) + wave_in_block, n_waves = gridDim.x * (EXTEND_BLOCK / 64);
     // A thread block owns EXTEND_BLOCK / 64 consecutive 64-ray blocks out of every n_waves of the queue; its waves take them
@@ -1411,17 +1439,22 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             }
             next += n_refill;
         }
-        // inner nodes
-        for (;;) {
-            const bool at_inner = is_inner(cur);
-            const unsigned long long m = __ballot(at_inner);
-            if (m == 0) break;
-            if ((int)__popcll(m) < inner_min) {
+        // inner nodes: as long as enough lanes are at one, or the lanes that are have nothing else to wait for.  (The decision
+        // is the same for the whole wave and is computed as one scalar value, so that the loop is a scalar loop: left as a
+        // loop with several exits, each costs every turn a handful of exec-mask instructions.)
+        auto node_turn_due = [&]() -> bool {
+            const unsigned long long m = __ballot(is_inner(cur));
+            int due = m != 0;
+            if (m != 0 && (int)__popcll(m) < inner_min) {
                 const unsigned long long m_prim = __ballot(is_prim(cur));
                 const unsigned long long m_med = __ballot(is_medium(cur));
-                if (m_prim != 0 || (int)__popcll(m_med) >= medium_min) break;
-                if (next < n && (int)__popcll(__ballot(cur >= REF_DONE)) >= refill_min) break;  // lanes free or about to be
+                if (m_prim != 0 || (int)__popcll(m_med) >= medium_min) due = 0;
+                else if (next < n && (int)__popcll(__ballot(cur >= REF_DONE)) >= refill_min) due = 0;  // lanes free or about to be
             }
+            return __ballot(due != 0) != 0ull;  // (a ballot's value is the same in every lane by construction)
+        };
+        while (node_turn_due()) {
+            const bool at_inner = is_inner(cur);
             moved = true;
 #if RT_LANE_STATS == 1
             if (COUNT) slots++;
@@ -1445,6 +1478,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
         // sphere and quad leaves
         {
             const bool at_prim = is_prim(cur);
+            const bool shallow = st.wave_is_shallow(0);  // (no lane's stack reaches into the global part: pops read LDS)
 #if RT_LANE_STATS == 2
             if (COUNT && __ballot(at_prim)) slots++;
 #endif
@@ -1452,7 +1486,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             if (at_prim) {
                 float t;
                 if (leaf_root<COUNT, true>(sc, cur, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr, r.inv)) { tmax = t; best = cur; }
-                cur = pop_next(st, tmax);
+                cur = shallow ? pop_next<true>(st, tmax) : pop_next(st, tmax);
             }
         }
         // media: once enough lanes wait at one, or when the wave has nothing else it could do
@@ -1479,7 +1513,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
                 }
             }
         }
-        eager = !moved;
+        eager = __ballot(!moved) != 0ull;
     }
 #ifdef RT_WAVE_TIMES
     if (lane == 0 && ((wave & 255u) == 0 || node_turns > RT_WAVE_TIMES)) printf("wave %u %u start %llu end %llu turns %u overflow %u\n", bounce, wave, t_start, wall_clock64(), node_turns, overflow_turns);

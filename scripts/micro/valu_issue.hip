@@ -42,7 +42,7 @@ typedef float float2v __attribute__((ext_vector_type(2)));
         for (int turn = 0; turn < TURNS; ++turn) {                                                                   \
             _Pragma("unroll") for (int rep = 0; rep < UNROLL / 16; ++rep) {                                          \
                 _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                     \
-                    asm volatile(ASM : "+v"(a[i]), "+v"(p[i]), "+v"(u[i]) : "v"(m), "v"(c), "v"(pm), "v"(um) : "vcc", "s20", "s21"); \
+                    asm volatile(ASM : "+v"(a[i]), "+v"(p[i]), "+v"(u[i]) : "v"(m), "v"(c), "v"(pm), "v"(um) : "vcc", "scc", "s20", "s21"); \
                 }                                                                                                    \
             }                                                                                                        \
         }                                                                                                            \
@@ -123,6 +123,13 @@ ISSUE_KERNEL(k_lshl_b64, "v_lshlrev_b64 %1, 1, %1")
 ISSUE_KERNEL(k_bfi, "v_bfi_b32 %2, %6, %2, %6")
 ISSUE_KERNEL(k_alignbit, "v_alignbit_b32 %2, %2, %6, 5")
 ISSUE_KERNEL(k_med3, "v_med3_f32 %0, %0, %3, %4")
+ISSUE_KERNEL(k_s_mov, "s_mov_b32 s20, 0")
+ISSUE_KERNEL(k_s_and_b64, "s_and_b64 s[20:21], s[20:21], exec")
+ISSUE_KERNEL(k_s_add, "s_add_u32 s20, s20, 1")
+ISSUE_KERNEL(k_s_bcnt, "s_bcnt1_i32_b64 s20, exec")
+ISSUE_KERNEL(k_s_nop, "s_nop 0")
+ISSUE_KERNEL(k_saveexec, "s_and_saveexec_b64 s[20:21], exec\n\ts_or_b64 exec, exec, s[20:21]")
+ISSUE_KERNEL(k_valu_salu, "v_add_f32 %0, %0, %4\n\ts_and_b64 s[20:21], s[20:21], exec")
 ISSUE_KERNEL(k_mix, "v_fma_f32 %0, %0, %3, %4\n\tv_pk_mul_f32 %1, %1, %5\n\tv_min_u32 %2, %2, %6")
 
 typedef void (*kernel_t)(unsigned long long*, float*, float);
@@ -184,6 +191,7 @@ int main() {
     RUN(k_div_scale, 1); RUN(k_div_fmas, 1); RUN(k_div_fixup, 1); RUN(k_addc_vcc, 1); RUN(k_addc_sgpr, 1); RUN(k_add_co, 1); RUN(k_mad_u64_u32, 1);
     RUN(k_cmp_class, 1); RUN(k_readfirstlane, 1); RUN(k_log, 1); RUN(k_exp, 1); RUN(k_rsq, 1); RUN(k_mul_f64, 1); RUN(k_lshl_b64, 1);
     RUN(k_bfi, 1); RUN(k_alignbit, 1); RUN(k_med3, 1);
+    RUN(k_s_mov, 1); RUN(k_s_and_b64, 1); RUN(k_s_add, 1); RUN(k_s_bcnt, 1); RUN(k_s_nop, 1); RUN(k_saveexec, 2); RUN(k_valu_salu, 2);
     RUN(k_mix, 3);
     return 0;
 }

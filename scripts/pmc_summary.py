@@ -36,6 +36,10 @@ for k, c in tot.items():
         # wall-clock based: assumes 2.4 GHz; VALU busy = issue cycles / (1024 SIMDs x cycles)
         cyc = dur[k] * 2.4e9
         res["valu_issue_share_at_2p4GHz"] = round(d.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (1024.0 * cyc), 3)
+        # the unambiguous form: vector instructions per SIMD and cycle (a SIMD retires at most one per 2.4 cycles of the
+        # cheap opcodes - add, mul, mov, logic - and one per 4.2 of fma, min / max, compares, conversions, packed ones:
+        # scripts/micro/valu_issue.hip)
+        res["valu_insts_per_simd_cycle_at_2p4GHz"] = round(d.get("SQ_INSTS_VALU", 0) / (1024.0 * cyc), 4)
         res["waves_per_simd_at_2p4GHz"] = round(d.get("SQ_WAVE_CYCLES", 0) * 4 / (1024.0 * cyc), 2)
     if d.get("TCC_HIT_sum") is not None:
         h, m = d.get("TCC_HIT_sum", 0), d.get("TCC_MISS_sum", 0)
