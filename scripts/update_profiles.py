@@ -1,5 +1,6 @@
 """Copies what scripts/final_profiles.sh left under gpurun_out/ into profiles/ and rewrites profiles/traffic.json from the
-new PMC summary.  usage: python scripts/update_profiles.py <tag in gpurun_out, e.g. r02d> <prefix in profiles, e.g. r02_c>"""
+new PMC summary.  usage: python scripts/update_profiles.py <tag in gpurun_out, e.g. r02d> <prefix in profiles, e.g. r02_c>
+[<tag of a scripts/pmc_c5.sh run>: the 10 M-sphere scene's counters, copied to <prefix>_pmc_c5_summary.json]"""
 import datetime, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, dst = sys.argv[1], sys.argv[2]
@@ -26,6 +27,17 @@ t["extend_issue"].update({"source": f"{src} (SQ passes, one pipeline, 16 spp of 
                           "wait_share_of_wave_cycles": e["wait_any_share_of_wave_cycles"],
                           "valu_insts_per_segment_wave": round(e["raw"]["SQ_INSTS_VALU"] / (segments / 64), 1),
                           "whole_step_valu_issue_share": round(valu * 4 / (1024 * 2.4e9 * secs), 3)})
+if len(sys.argv) > 3:  # the 10 M-sphere scene (scripts/pmc_c5.sh): memory-side read traffic of the extend kernel
+    shutil.copy(f"{G}/pmc_{sys.argv[3]}/summary.json", f"{P}/{dst}_pmc_c5_summary.json")
+    c5 = next(v for k, v in json.load(open(f"{P}/{dst}_pmc_c5_summary.json")).items() if k.startswith("rt::k_extend<false"))
+    r = c5["raw"]
+    read_bytes = r["TCC_EA0_RDREQ_128B_sum"] * 128 + r["TCC_EA0_RDREQ_64B_sum"] * 64 + r["TCC_EA0_RDREQ_32B_sum"] * 32
+    t["c5"] = {"source": f"profiles/{dst}_pmc_c5_summary.json (10 M spheres 1920x1080, depth 2, 3 calls of 16 spp; scripts/pmc_c5.sh)",
+               "kernel": "k_extend", "seconds": c5["seconds_profiled"], "dispatches": c5["dispatches"],
+               "memory_side_read_bytes": read_bytes, "memory_side_gbs": round(read_bytes / c5["seconds_profiled"] / 1e9, 1),
+               "l2_hit_rate": round(r["TCC_HIT_sum"] / (r["TCC_HIT_sum"] + r["TCC_MISS_sum"]), 4),
+               "note": "read requests of the L2 to the fabric (TCC_EA0_RDREQ by size, Infinity Cache hits included) over the "
+                       "extend launches' time: what the node and sphere gathers pull in; write traffic (hit records) is 1 % of it"}
 # which code the numbers belong to: the commit the working tree was at when they were copied in, and the day
 t["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
 t["date"] = datetime.date.today().isoformat()
