@@ -389,6 +389,9 @@ struct PrivateStack {  // per-lane array (scratch memory): used by the record-ba
         return true;
     }
     RT_D bool wave_is_shallow(int) const { return false; }
+    static constexpr bool HAS_LDS_POP = false;
+    RT_D uint32_t pop_next_in_lds(float, uint32_t, uint32_t keep) { return keep; }
+    RT_D uint32_t finish_node_in_lds(float, uint32_t, uint32_t r0, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { return r0; }
 };
 
 // Stack of the render path's extend kernel.  An entry is 64 bits: (entry distance << 32) | ref.
@@ -402,6 +405,7 @@ typedef __attribute__((address_space(1))) unsigned long long global_u64;
 template <int LEVELS, bool OVERFLOW = true>
 struct WaveStack {
     static constexpr bool ANY_INTERVAL = false;  // its rays are a render's: t_min = 0.001
+    static constexpr bool HAS_LDS_POP = true;
     lds_u64* lds;     // this lane's column: level k at lds[64 * k]
     global_u64* ovf;  // the wave's area (the same pointer in all its lanes, so it lives in scalar registers): level LEVELS + k of lane l at ovf[64 * k + l]
     uint32_t lane;
@@ -427,6 +431,93 @@ struct WaveStack {
     // stay in LDS for every lane.  One comparison per node for the wave, instead of one branch per push and pop and lane:
     // the scalar instructions of those branches (exec-mask bookkeeping) are what the extend kernel's time is most sensitive to.
     RT_D bool wave_is_shallow(int room) const { return !OVERFLOW || __ballot(sp > LEVELS - room) == 0ull; }
+    // pop_next (below) for the lanes with `need` set, entries in LDS only (wave_is_shallow(0)); the other lanes get `keep`.
+    // Written out: the lanes that still look for an entry are the exec mask, a lane leaves when its stack is empty or its
+    // entry can hold a closer hit, and the wave leaves when no lane is left - three scalar instructions and two branches a
+    // round, where the compiler's code for the same loop keeps its own masks beside exec (fourteen).
+    // The end of a node step in one piece, entries in LDS only (wave_is_shallow(3)): keys in ascending order with ~0 for a
+    // child that was missed; the hit children other than the nearest go on the stack farthest first, a lane with no hit at
+    // all pops (as pop_next_in_lds); returns the next reference.
+    RT_D uint32_t finish_node_in_lds(float tmax, uint32_t k0, uint32_t r0, uint32_t k1, uint32_t r1, uint32_t k2, uint32_t r2, uint32_t k3,
+                                     uint32_t r3) {
+        uint32_t out = r0;
+        uint32_t addr, lo, hi;
+        unsigned long long saved, m1, m2, m3;
+        const uint32_t base = (uint32_t)(uintptr_t)lds;
+        asm volatile(
+            // (every comparison while all of the step's lanes are active: a comparison leaves the bits of inactive lanes 0)
+            "v_cmp_ne_u32_e64 %[m3], -1, %[k3]\n\t"
+            "v_cmp_ne_u32_e64 %[m2], -1, %[k2]\n\t"
+            "v_cmp_ne_u32_e64 %[m1], -1, %[k1]\n\t"
+            "v_cmp_eq_u32 vcc, -1, %[k0]\n\t"
+            "s_mov_b64 %[saved], exec\n\t"
+            "s_and_b64 exec, %[saved], %[m3]\n\t"
+            "v_lshl_add_u32 %[addr], %[sp], 9, %[base]\n\t"
+            "ds_write2_b32 %[addr], %[r3], %[k3] offset1:1\n\t"
+            "v_add_u32 %[sp], 1, %[sp]\n\t"
+            "s_and_b64 exec, %[saved], %[m2]\n\t"
+            "v_lshl_add_u32 %[addr], %[sp], 9, %[base]\n\t"
+            "ds_write2_b32 %[addr], %[r2], %[k2] offset1:1\n\t"
+            "v_add_u32 %[sp], 1, %[sp]\n\t"
+            "s_and_b64 exec, %[saved], %[m1]\n\t"
+            "v_lshl_add_u32 %[addr], %[sp], 9, %[base]\n\t"
+            "ds_write2_b32 %[addr], %[r1], %[k1] offset1:1\n\t"
+            "v_add_u32 %[sp], 1, %[sp]\n\t"
+            "s_and_b64 exec, %[saved], vcc\n\t"
+            "s_cbranch_execz 2f\n\t"
+            "v_mov_b32 %[out], -2\n"
+            "1:\n\t"
+            "v_cmp_lt_i32 vcc, 0, %[sp]\n\t"
+            "s_and_b64 exec, exec, vcc\n\t"
+            "s_cbranch_execz 2f\n\t"
+            "v_add_u32 %[sp], -1, %[sp]\n\t"
+            "v_lshl_add_u32 %[addr], %[sp], 9, %[base]\n\t"
+            "ds_read_b32 %[lo], %[addr]\n\t"
+            "ds_read_b32 %[hi], %[addr] offset:4\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_le_f32 vcc, %[hi], %[tmax]\n\t"
+            "v_cndmask_b32 %[out], %[out], %[lo], vcc\n\t"
+            "s_andn2_b64 exec, exec, vcc\n\t"
+            "s_cbranch_execnz 1b\n"
+            "2:\n\t"
+            "s_mov_b64 exec, %[saved]"
+            : [out] "+v"(out), [sp] "+v"(sp), [addr] "=&v"(addr), [lo] "=&v"(lo), [hi] "=&v"(hi), [saved] "=&s"(saved), [m1] "=&s"(m1),
+              [m2] "=&s"(m2), [m3] "=&s"(m3)
+            : [k0] "v"(k0), [k1] "v"(k1), [r1] "v"(r1), [k2] "v"(k2), [r2] "v"(r2), [k3] "v"(k3), [r3] "v"(r3), [base] "v"(base), [tmax] "v"(tmax)
+            : "vcc", "scc", "memory");
+        static_assert(REF_DONE == 0xFFFFFFFEu, "the assembly above spells REF_DONE as -2");
+        return out;
+    }
+    // The lanes that pop are those whose `probe` is ~0 (a node step hands in its nearest child's key: ~0 says no child was hit).
+    RT_D uint32_t pop_next_in_lds(float tmax, uint32_t probe, uint32_t keep) {
+        uint32_t out = probe == 0xFFFFFFFFu ? REF_DONE : keep;
+        uint32_t addr, lo, hi;
+        unsigned long long saved;
+        const uint32_t base = (uint32_t)(uintptr_t)lds;
+        asm volatile(
+            "v_cmp_eq_u32 vcc, -1, %[probe]\n\t"
+            "s_and_saveexec_b64 %[saved], vcc\n\t"
+            "s_cbranch_execz 2f\n"
+            "1:\n\t"
+            "v_cmp_lt_i32 vcc, 0, %[sp]\n\t"
+            "s_and_b64 exec, exec, vcc\n\t"
+            "s_cbranch_execz 2f\n\t"
+            "v_add_u32 %[sp], -1, %[sp]\n\t"
+            "v_lshl_add_u32 %[addr], %[sp], 9, %[base]\n\t"
+            "ds_read_b32 %[lo], %[addr]\n\t"
+            "ds_read_b32 %[hi], %[addr] offset:4\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_le_f32 vcc, %[hi], %[tmax]\n\t"
+            "v_cndmask_b32 %[out], %[out], %[lo], vcc\n\t"
+            "s_andn2_b64 exec, exec, vcc\n\t"
+            "s_cbranch_execnz 1b\n"
+            "2:\n\t"
+            "s_mov_b64 exec, %[saved]"
+            : [out] "+v"(out), [sp] "+v"(sp), [addr] "=&v"(addr), [lo] "=&v"(lo), [hi] "=&v"(hi), [saved] "=&s"(saved)
+            : [probe] "v"(probe), [base] "v"(base), [tmax] "v"(tmax)
+            : "vcc", "scc", "memory");
+        return out;
+    }
 };
 
 // Start of the interval of every ray of a render (src/camera.rs:346: Interval::new(0.001, f32::MAX)); rays that come with
@@ -663,6 +754,7 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
     order2(key[1], ref[1], key[3], ref[3]);
     order2(key[1], ref[1], key[2], ref[2]);
     if (st.wave_is_shallow(3)) {  // the usual case: neither the pushes nor the pops of this node can leave the LDS levels
+        if (Stack::HAS_LDS_POP) return st.finish_node_in_lds(tmax, key[0], ref[0], key[1], ref[1], key[2], ref[2], key[3], ref[3]);
         if (key[0] == 0xFFFFFFFFu) return pop_next<true>(st, tmax);
         if (key[3] != 0xFFFFFFFFu) st.template push<true>(ref[3], __uint_as_float(key[3]));
         if (key[2] != 0xFFFFFFFFu) st.template push<true>(ref[2], __uint_as_float(key[2]));
@@ -1443,15 +1535,17 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
         // is the same for the whole wave and is computed as one scalar value, so that the loop is a scalar loop: left as a
         // loop with several exits, each costs every turn a handful of exec-mask instructions.)
         auto node_turn_due = [&]() -> bool {
-            const unsigned long long m = __ballot(is_inner(cur));
-            int due = m != 0;
-            if (m != 0 && (int)__popcll(m) < inner_min) {
-                const unsigned long long m_prim = __ballot(is_prim(cur));
-                const unsigned long long m_med = __ballot(is_medium(cur));
-                if (m_prim != 0 || (int)__popcll(m_med) >= medium_min) due = 0;
+            // (counts, not masks compared with zero: the compiler keeps a test of a ballot against zero as a per-lane
+            // condition, and the loop would be one that each lane leaves for itself)
+            const int n_inner = (int)__popcll(__ballot(is_inner(cur)));
+            int due = n_inner;
+            if (n_inner != 0 && n_inner < inner_min) {
+                const int n_prim = (int)__popcll(__ballot(is_prim(cur))), n_med = (int)__popcll(__ballot(is_medium(cur)));
+                if (n_prim != 0 || n_med >= medium_min) due = 0;
                 else if (next < n && (int)__popcll(__ballot(cur >= REF_DONE)) >= refill_min) due = 0;  // lanes free or about to be
             }
-            return __ballot(due != 0) != 0ull;  // (a ballot's value is the same in every lane by construction)
+            asm volatile("" : "+s"(due));  // (a value in a scalar register is the same in every lane by construction)
+            return due != 0;
         };
         while (node_turn_due()) {
             const bool at_inner = is_inner(cur);
@@ -1486,7 +1580,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             if (at_prim) {
                 float t;
                 if (leaf_root<COUNT, true>(sc, cur, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr, r.inv)) { tmax = t; best = cur; }
-                cur = shallow ? pop_next<true>(st, tmax) : pop_next(st, tmax);
+                cur = shallow ? st.pop_next_in_lds(tmax, 0xFFFFFFFFu, 0u) : pop_next(st, tmax);
             }
         }
         // media: once enough lanes wait at one, or when the wave has nothing else it could do
