@@ -811,6 +811,35 @@ RT_D bool sphere_box_test(float4 s, const TravRay& r, float tmax, bool try_insid
 // glass ball filled with fog, or the mist that fills a whole scene inside its boundary sphere) is
 // one quadratic: both leaves take their roots from it, in the order and with the intervals they
 // would have had one after the other.
+// The pair "sphere leaf, then the medium that this same sphere bounds": one quadratic, whose two roots serve the sphere leaf
+// and both boundary queries of the medium.
+template <bool COUNT, class Key>
+RT_D void sphere_and_its_medium(float4 s, const DMedium& m, uint32_t sphere_ref, uint32_t medium_ref, bool origin_inside, const TravRay& r,
+                                float& tmax, uint32_t& best, const Key& key, Probe& pr) {
+    if (COUNT) { pr.spheres += 3; pr.media++; }
+    float near_root, far_root;
+    if (sphere_roots(f3(s), s.w, r.o, r.d, r.a, near_root, far_root)) {
+        float root = near_root;
+        bool in = r.tmin < root && root < tmax;
+        if (!in) {
+            root = far_root;
+            in = r.tmin < root && root < tmax;
+        }
+        if (in && sphere_box_test(s, r, tmax, origin_inside)) {
+            tmax = root;
+            best = sphere_ref;
+        }
+        float t1, t2, t;
+        if (medium_span_of_roots(near_root, far_root, t1, t2) && medium_sample(m, ref_index(medium_ref), t1, t2, r.a, r.tmin, tmax, key, t)) {
+            tmax = t;
+            best = medium_ref;
+        }
+    }
+}
+RT_D bool medium_is_bounded_by(const DMedium& m, float4 s) {
+    return m.single_sphere && m.sphere.x == s.x && m.sphere.y == s.y && m.sphere.z == s.z && m.sphere.w == s.w;
+}
+
 template <bool COUNT, bool GENERIC, class Key>
 RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_t& best, const Key& key, Probe& pr) {
     for (uint32_t g = 0; g < sc.n_global; ++g) {
@@ -824,27 +853,8 @@ RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_
             const uint32_t next = g + 1 < sc.n_global ? sc.global_refs[g + 1] : REF_NONE;
             if (next != REF_NONE && ref_kind(next) == KIND_MEDIUM) {
                 const DMedium m = load_medium(sc.media + ref_index(next));
-                if (m.single_sphere && m.sphere.x == s.x && m.sphere.y == s.y && m.sphere.z == s.z && m.sphere.w == s.w) {
-                    if (COUNT) { pr.spheres += 3; pr.media++; }
-                    float near_root, far_root;
-                    if (sphere_roots(f3(s), s.w, r.o, r.d, r.a, near_root, far_root)) {
-                        float root = near_root;
-                        bool in = r.tmin < root && root < tmax;
-                        if (!in) {
-                            root = far_root;
-                            in = r.tmin < root && root < tmax;
-                        }
-                        if (in && sphere_box_test(s, r, tmax, (sc.global_inside >> g) & 1u)) {
-                            tmax = root;
-                            best = ref;
-                        }
-                        float t1, t2;
-                        if (medium_span_of_roots(near_root, far_root, t1, t2) &&
-                            medium_sample(m, ref_index(next), t1, t2, r.a, r.tmin, tmax, key, t)) {
-                            tmax = t;
-                            best = next;
-                        }
-                    }
+                if (medium_is_bounded_by(m, s)) {
+                    sphere_and_its_medium<COUNT>(s, m, ref, next, (sc.global_inside >> g) & 1u, r, tmax, best, key, pr);
                     ++g;
                     continue;
                 }
@@ -1623,13 +1633,31 @@ __global__ __launch_bounds__(256) void k_first_leaves(DScene sc, BatchInfo b, ui
                                                       const float4* __restrict__ ray_d, uint2* __restrict__ hits, DCounters* counters) {
     const uint32_t n = counts[bounce];
     Probe pr;
+    // The one shape the reference's scenes have (a big sphere and the mist it bounds: the Book-2 scene) with the two records read
+    // once, ahead of the rays: inside the loop over the rays they are read again for every ray, each read a scalar load the
+    // wave waits for.
+    bool pair = false;
+    uint32_t ref0 = REF_NONE, ref1 = REF_NONE;
+    float4 s = make_float4(0, 0, 0, 0);
+    DMedium m{};
+    if (sc.n_global == 2) {
+        ref0 = sc.global_refs[0];
+        ref1 = sc.global_refs[1];
+        if (ref_is_leaf(ref0) && ref_kind(ref0) == KIND_SPHERE && !ref_placed(ref0) && ref_kind(ref1) == KIND_MEDIUM) {
+            s = sc.spheres[ref_index(ref0)];
+            m = load_medium(sc.media + ref_index(ref1));
+            pair = medium_is_bounded_by(m, s);
+        }
+    }
+    const bool origin_inside = (sc.global_inside & 1u) != 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 ro = ray_o[i], rd = ray_d[i];
         BatchMediumKey key{seed, __float_as_uint(rd.w), bounce, b};
         TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, RENDER_TMIN);
         float tmax = RT_INF;
         uint32_t best = REF_NONE;
-        global_leaves<COUNT, GENERIC>(sc, r, tmax, best, key, pr);
+        if (pair) sphere_and_its_medium<COUNT>(s, m, ref0, ref1, origin_inside, r, tmax, best, key, pr);
+        else global_leaves<COUNT, GENERIC>(sc, r, tmax, best, key, pr);
         hits[i] = make_uint2(__float_as_uint(tmax), best);
     }
     if (COUNT) flush_probe(counters, pr, 0, 0);
