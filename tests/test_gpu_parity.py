@@ -738,6 +738,26 @@ def test_render_is_independent_of_batching_and_sample_splits():
     a.render_accumulate_host(host, first_sample=7, n_samples=1, seed=3)   # back to the pageable buffer
     del locked
     a._check(a.amd.rt_host_buffer_destroy(a.ctx, p))
+    # The caller's own buffer kept registered between calls is an option (off by default: nothing of the caller's memory stays
+    # registered after a call).  With it on, a buffer that is freed and whose address the allocator hands out again - the same
+    # pointer and size, another mapping - must still give the right image, and so must the calls after the option went off.
+    a.set_host_buffer_pinning(True)
+    for first in (1, 3):
+        again = np.zeros((40, 64, 4), np.float32)
+        a.render_accumulate_host(again, first_sample=1, n_samples=2, seed=3)
+        a.render_accumulate_host(again, first_sample=3, n_samples=4, seed=3)
+        assert np.array_equal(again[..., :3], whole[..., :3]), first
+        a.release_host_buffer()   # what a caller owes before freeing a buffer while the option is on
+        del again
+    kept = np.zeros((40, 64, 4), np.float32)
+    a.render_accumulate_host(kept, first_sample=1, n_samples=6, seed=3)
+    a.set_host_buffer_pinning(False)   # releases the registration
+    a.render_accumulate_host(kept, first_sample=7, n_samples=1, seed=3)
+    a.render_accumulate_host(host, first_sample=8, n_samples=1, seed=3)
+    other = rt.Scene.builtin(8, 64, 40)
+    other.set_seed(3)
+    other.render_samples(7)
+    assert np.array_equal(kept[..., :3], other.accumulator()[..., :3])
 
 
 def test_contexts_of_several_host_threads_render_side_by_side():
