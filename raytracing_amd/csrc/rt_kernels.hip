@@ -868,6 +868,38 @@ RT_D void global_leaves(const DScene& sc, const TravRay& r, float& tmax, uint32_
     }
 }
 
+// The one shape the reference's scenes have (a big sphere and the mist it bounds: the Book-2 scene) with its two records read
+// once per thread, ahead of the rays: read inside a loop over rays or bounces they are scalar loads that the wave waits for, every
+// time round.  Any other set of leaves goes through global_leaves.
+struct FirstLeaves {
+    bool pair = false;
+    bool origin_inside = false;
+    uint32_t ref0 = REF_NONE, ref1 = REF_NONE;
+    float4 s;
+    DMedium m;
+};
+RT_D FirstLeaves load_first_leaves(const DScene& sc) {
+    FirstLeaves f;
+    f.s = make_float4(0, 0, 0, 0);
+    f.m = DMedium{};
+    if (sc.n_global == 2) {
+        f.ref0 = sc.global_refs[0];
+        f.ref1 = sc.global_refs[1];
+        if (ref_is_leaf(f.ref0) && ref_kind(f.ref0) == KIND_SPHERE && !ref_placed(f.ref0) && ref_kind(f.ref1) == KIND_MEDIUM) {
+            f.s = sc.spheres[ref_index(f.ref0)];
+            f.m = load_medium(sc.media + ref_index(f.ref1));
+            f.pair = medium_is_bounded_by(f.m, f.s);
+        }
+    }
+    f.origin_inside = (sc.global_inside & 1u) != 0;
+    return f;
+}
+template <bool COUNT, bool GENERIC, class Key>
+RT_D void first_leaves(const DScene& sc, const FirstLeaves& f, const TravRay& r, float& tmax, uint32_t& best, const Key& key, Probe& pr) {
+    if (f.pair) sphere_and_its_medium<COUNT>(f.s, f.m, f.ref0, f.ref1, f.origin_inside, r, tmax, best, key, pr);
+    else global_leaves<COUNT, GENERIC>(sc, r, tmax, best, key, pr);
+}
+
 // Starting point of a ray's traversal when the scene keeps leaves out of the tree: the closest
 // hit among those leaves, as the hit record the extend kernel then improves on.  Ray generation
 // computes it with the ray still in registers; for the rays shade creates, a streaming pass of
@@ -1633,31 +1665,14 @@ __global__ __launch_bounds__(256) void k_first_leaves(DScene sc, BatchInfo b, ui
                                                       const float4* __restrict__ ray_d, uint2* __restrict__ hits, DCounters* counters) {
     const uint32_t n = counts[bounce];
     Probe pr;
-    // The one shape the reference's scenes have (a big sphere and the mist it bounds: the Book-2 scene) with the two records read
-    // once, ahead of the rays: inside the loop over the rays they are read again for every ray, each read a scalar load the
-    // wave waits for.
-    bool pair = false;
-    uint32_t ref0 = REF_NONE, ref1 = REF_NONE;
-    float4 s = make_float4(0, 0, 0, 0);
-    DMedium m{};
-    if (sc.n_global == 2) {
-        ref0 = sc.global_refs[0];
-        ref1 = sc.global_refs[1];
-        if (ref_is_leaf(ref0) && ref_kind(ref0) == KIND_SPHERE && !ref_placed(ref0) && ref_kind(ref1) == KIND_MEDIUM) {
-            s = sc.spheres[ref_index(ref0)];
-            m = load_medium(sc.media + ref_index(ref1));
-            pair = medium_is_bounded_by(m, s);
-        }
-    }
-    const bool origin_inside = (sc.global_inside & 1u) != 0;
+    const FirstLeaves fl = load_first_leaves(sc);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 ro = ray_o[i], rd = ray_d[i];
         BatchMediumKey key{seed, __float_as_uint(rd.w), bounce, b};
         TravRay r = make_trav_ray(f3(ro), f3(rd), ro.w, RENDER_TMIN);
         float tmax = RT_INF;
         uint32_t best = REF_NONE;
-        if (pair) sphere_and_its_medium<COUNT>(s, m, ref0, ref1, origin_inside, r, tmax, best, key, pr);
-        else global_leaves<COUNT, GENERIC>(sc, r, tmax, best, key, pr);
+        first_leaves<COUNT, GENERIC>(sc, fl, r, tmax, best, key, pr);
         hits[i] = make_uint2(__float_as_uint(tmax), best);
     }
     if (COUNT) flush_probe(counters, pr, 0, 0);
