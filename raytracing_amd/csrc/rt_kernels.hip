@@ -924,9 +924,14 @@ template <bool COUNT, bool GENERIC, class Stack, class Key>
 RT_D void walk_tree(const DScene& sc, const TravRay& r, float& tmax, uint32_t& best, const Key& key, Stack& st, Probe& pr) {
     const NodeSource src{sc.nodes, nullptr, 0};
     uint32_t cur = sc.root == REF_NONE ? REF_DONE : sc.root;
-    while (cur != REF_DONE) {
-        if (!ref_is_leaf(cur)) cur = node_step<COUNT, false>(src, r, cur, tmax, st, pr);
-        else cur = leaf_step<COUNT, GENERIC>(sc, r, cur, tmax, best, key, st, pr);
+    // (the loop as one the wave leaves as a whole, its decisions made from counts: see the extend kernel's node loop)
+    for (;;) {
+        int n_inner = (int)__popcll(__ballot((int32_t)cur >= 0));  // inner nodes have no leaf bit; REF_DONE has
+        int n_leaf = (int)__popcll(__ballot(cur < REF_DONE && ref_is_leaf(cur)));
+        asm volatile("" : "+s"(n_inner), "+s"(n_leaf));
+        if (n_inner + n_leaf == 0) break;
+        if (n_inner != 0 && (int32_t)cur >= 0) cur = node_step<COUNT, false>(src, r, cur, tmax, st, pr);
+        if (cur < REF_DONE && ref_is_leaf(cur)) cur = leaf_step<COUNT, GENERIC>(sc, r, cur, tmax, best, key, st, pr);
     }
 }
 
