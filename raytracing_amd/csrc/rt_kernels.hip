@@ -781,6 +781,7 @@ RT_D uint32_t leaf_step(const DScene& sc, const TravRay& r, uint32_t cur, float&
         tmax = t;
         best = cur;
     }
+    if (Stack::HAS_LDS_POP && st.wave_is_shallow(0)) return st.pop_next_in_lds(tmax, 0xFFFFFFFFu, 0u);
     return pop_next(st, tmax);
 }
 
