@@ -1456,8 +1456,12 @@ static constexpr int OVERFLOW_STACK = STACK_SIZE - MIN_LDS_STACK;
 #ifndef RT_EXTEND_WAVES
 #define RT_EXTEND_WAVES 7  // resident waves per SIMD the register allocation aims for (72 registers)
 #endif
+#ifndef RT_EXTEND_WAVES_GENERIC
+#define RT_EXTEND_WAVES_GENERIC 7  // the same for scenes whose media have boxes or hulls as boundaries: 71 registers, a few
+                                   // scalar registers kept in spare vector lanes (Cornell smoke 1024x1024x16: 12.4 ms at five waves, 11.5 at seven)
+#endif
 template <bool COUNT, bool SMALL_TREE, bool GENERIC, bool OVERFLOW = true>
-__global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GENERIC ? 5 : RT_EXTEND_WAVES, GENERIC ? 5 : RT_EXTEND_WAVES))) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
+__global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GENERIC ? RT_EXTEND_WAVES_GENERIC : RT_EXTEND_WAVES, GENERIC ? RT_EXTEND_WAVES_GENERIC : RT_EXTEND_WAVES))) void k_extend(DScene sc, BatchInfo b, uint64_t seed, uint32_t bounce,
                                                          const uint32_t* __restrict__ counts, const float4* __restrict__ ray_o,
                                                          const float4* __restrict__ ray_d, uint2* __restrict__ hits,
                                                          unsigned long long* __restrict__ stack_overflow, ExtendTuning tune,
