@@ -298,7 +298,7 @@ def other_configs(rt, device):
             # memory-side traffic needs counters - see from_profiles.c5)
             visits = cnt["node_visits"] / max(1, cnt["samples"]) * w * h * spp
             row["extend_node_visits_per_s"] = round(visits / (ext_ms * 1e-3) / 1e9, 2)
-            row["extend_node_visits_unit"] = "G node visits / s (128-byte nodes), k_extend's own time"
+            row["extend_node_visits_unit"] = "G node visits / s (64-byte nodes), k_extend's own time"
         out[name] = row
         scene.close()
     return out
