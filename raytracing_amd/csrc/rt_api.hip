@@ -537,8 +537,8 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
 #endif
         c->tail_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)tail_per_cu;
 #ifdef RT_DEV_KNOBS
-        if (const char* e = getenv("RT_AMD_EXTEND_TUNING"))  // "inner,refill,medium"
-            sscanf(e, "%d,%d,%d", &c->tune.inner_min, &c->tune.refill_min, &c->tune.medium_min);
+        if (const char* e = getenv("RT_AMD_EXTEND_TUNING"))  // "inner,refill,medium,quad"
+            sscanf(e, "%d,%d,%d,%d", &c->tune.inner_min, &c->tune.refill_min, &c->tune.medium_min, &c->tune.quad_min);
         if (const char* e = getenv("RT_AMD_TAIL_RAYS")) c->tail_rays = (uint32_t)std::max(1, atoi(e));
         if (const char* e = getenv("RT_AMD_PIPES")) c->n_pipes = std::min(MAX_PIPES, std::max(1, atoi(e)));
         if (getenv("RT_AMD_VERBOSE"))

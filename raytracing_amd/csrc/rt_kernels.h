@@ -39,6 +39,7 @@ struct ExtendTuning {
     int medium_min = 0;   // run the medium test once this many lanes wait at a medium; 0: chosen per scene (4 when every
                           // medium in the tree is bounded by one sphere - a short test -, 24 when some boundary is a list
                           // of leaves, whose test runs to several hundred instructions)
+    int quad_min = 6;     // run the quad test once this many lanes wait at a quad
 };
 int extend_blocks_per_cu(bool counting, bool generic_media);  // generic_media: the variant for scenes with DScene::generic_media set
 // stack levels per lane the extend kernel keeps in LDS for a tree of n_nodes nodes; deeper levels go to the overflow area

@@ -95,17 +95,25 @@ RT_D void quad_alpha_beta(float4 qq, float4 uu, float4 vv, float3 p, float& alph
 // leaf_root).  inv = 1 / d, used by that test only.
 RT_D bool own_box_test(float4 mn, float4 mx, float3 o, float3 inv, float lo, float hi);
 RT_D bool own_box_test_of_walk(float4 mn, float4 mx, float3 o, float3 d, float3 inv, float lo, float hi);
+template <bool ONE_TRIP = false>
 RT_D bool quad_root(const float4* __restrict__ q4, float4 nd, float3 o, float3 d, float tmin, float tmax, float& t,
                     const float4* __restrict__ own_box = nullptr, float3 inv = make_float3(0.0f, 0.0f, 0.0f)) {
+    // ONE_TRIP: the three remaining records (the same 64-byte line as the first) and the box are asked for before the plane
+    // test has said that they are needed
+    float4 qq, uu, vv, mn = make_float4(0, 0, 0, 0), mx = mn;
+    if (ONE_TRIP) {
+        qq = get4(q4 + 1), uu = get4(q4 + 2), vv = get4(q4 + 3);
+        if (own_box) { mn = get4(own_box); mx = get4(own_box + 1); }
+    }
     float3 N = f3(nd);
     float denom = dot3(N, d);
     if (fabsf(denom) < 1e-8f) return false;
     float tt = (nd.w - dot3(N, o)) / denom;
     if (!(tmin <= tt && tt <= tmax)) return false;
-    // the three remaining records (and the quad's own box) in one round trip
-    const float4 qq = get4(q4 + 1), uu = get4(q4 + 2), vv = get4(q4 + 3);
-    float4 mn = make_float4(0, 0, 0, 0), mx = mn;
-    if (own_box) { mn = get4(own_box); mx = get4(own_box + 1); }
+    if (!ONE_TRIP) {  // the three remaining records (and the quad's own box) in one round trip
+        qq = get4(q4 + 1), uu = get4(q4 + 2), vv = get4(q4 + 3);
+        if (own_box) { mn = get4(own_box); mx = get4(own_box + 1); }
+    }
     const float3 h = (o + tt * d) - f3(qq), w = f3(qq.w, uu.w, vv.w);
     const float alpha = dot3(w, cross3(h, f3(vv)));
     if (!(0.0f <= alpha && alpha <= 1.0f)) return false;
@@ -170,47 +178,62 @@ RT_D bool leaf_root_in_leaf_space(const DScene& sc, uint32_t ref, float3 o, floa
 // numbers at its distance, a quad's thin box far along a ray - the reference's outcome is the one reproduced.  A placed
 // leaf's box is tested in object space by the reference, inside its Move / RotateY, and is not reproduced.  The box
 // travels with the leaf's record (one round trip).  inv = 1 / d.
+template <bool OWN_BOX> RT_D bool leaf_tests_own_box(uint32_t ref) {
+#ifdef RT_NO_OWN_BOX  // timing experiments only (development builds): results differ where the reference's box test fails
+    return false;
+#else
+    return OWN_BOX && RT_BVH_WIDTH == 4 && !ref_placed(ref);
+#endif
+}
+// a sphere, still or moving: the two kinds share one copy of the root computation
+template <bool COUNT, bool OWN_BOX = false>
+RT_D bool sphere_leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float time, float a, float tmin, float tmax, float& t, Probe& pr,
+                           float3 inv = make_float3(0.0f, 0.0f, 0.0f)) {
+    const uint32_t kind = ref_kind(ref), idx = ref_index(ref);
+    const bool own_box = leaf_tests_own_box<OWN_BOX>(ref);
+    if (COUNT) pr.spheres++;
+    float4 s;
+    float3 c;
+    const float4* xf;
+    float4 mn = make_float4(0, 0, 0, 0), mx = mn;
+    // (each kind reads its own arrays inside its branch: a pointer chosen by kind and used after the branches is a table
+    // in scratch memory and a flat load to the compiler)
+    if (kind == KIND_SPHERE) {
+        s = get4(sc.spheres + idx);
+        if (own_box) { mn = get4(sc.sphere_boxes + 2 * (size_t)idx); mx = get4(sc.sphere_boxes + 2 * (size_t)idx + 1); }
+        c = f3(s);
+        xf = sc.sphere_xf + 2 * (size_t)idx;
+    } else {
+        s = get4(sc.moving + 2 * (size_t)idx);
+        const float4 dc = get4(sc.moving + 2 * (size_t)idx + 1);
+        if (own_box) { mn = get4(sc.moving_boxes + 2 * (size_t)idx); mx = get4(sc.moving_boxes + 2 * (size_t)idx + 1); }
+        c = f3(s) + time * f3(dc);  // MovingSphere::hit, src/hittable.rs:310
+        xf = sc.moving_xf + 2 * (size_t)idx;
+    }
+    if (ref_placed(ref)) {
+        ray_to_object(xf[0], xf[1], o, d);
+        a = dot3(d, d);
+    }
+    return sphere_root(c, s.w, o, d, a, tmin, tmax, t) && (!own_box || own_box_test_of_walk(mn, mx, o, d, inv, tmin, tmax));
+}
+template <bool COUNT, bool OWN_BOX = false>
+RT_D bool quad_leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float tmin, float tmax, float& t, Probe& pr,
+                         float3 inv = make_float3(0.0f, 0.0f, 0.0f)) {
+    const uint32_t idx = ref_index(ref);
+    const bool own_box = leaf_tests_own_box<OWN_BOX>(ref);
+    if (COUNT) pr.quads++;
+    const float4* q4 = sc.quads + 4 * (size_t)idx;
+    const float4 nd = get4(q4);  // on its way while the placement is read and applied
+    if (ref_placed(ref)) ray_to_object(sc.quad_xf[2 * (size_t)idx], sc.quad_xf[2 * (size_t)idx + 1], o, d);
+    // (in the tree walk the quads of a wave are tested together, a handful at a time: there one round trip for all of a quad's
+    // records is worth more than the reads it saves to ask for three of them only after the plane test)
+    return quad_root<OWN_BOX>(q4, nd, o, d, tmin, tmax, t, own_box ? sc.quad_boxes + 2 * (size_t)idx : nullptr, inv);
+}
 template <bool COUNT, bool OWN_BOX = false>
 RT_D bool leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float time, float a, float tmin, float tmax, float& t, Probe& pr,
                     float3 inv = make_float3(0.0f, 0.0f, 0.0f)) {
-    const uint32_t kind = ref_kind(ref), idx = ref_index(ref);
-#ifdef RT_NO_OWN_BOX  // timing experiments only (development builds): results differ where the reference's box test fails
-    const bool own_box = false;
-#else
-    const bool own_box = OWN_BOX && RT_BVH_WIDTH == 4 && !ref_placed(ref);
-#endif
-    if (kind != KIND_QUAD) {  // a sphere, still or moving: the two kinds share one copy of the root computation
-        if (COUNT) pr.spheres++;
-        float4 s;
-        float3 c;
-        const float4* xf;
-        float4 mn = make_float4(0, 0, 0, 0), mx = mn;
-        // (each kind reads its own arrays inside its branch: a pointer chosen by kind and used after the branches is a table
-        // in scratch memory and a flat load to the compiler)
-        if (kind == KIND_SPHERE) {
-            s = get4(sc.spheres + idx);
-            if (own_box) { mn = get4(sc.sphere_boxes + 2 * (size_t)idx); mx = get4(sc.sphere_boxes + 2 * (size_t)idx + 1); }
-            c = f3(s);
-            xf = sc.sphere_xf + 2 * (size_t)idx;
-        } else {
-            s = get4(sc.moving + 2 * (size_t)idx);
-            const float4 dc = get4(sc.moving + 2 * (size_t)idx + 1);
-            if (own_box) { mn = get4(sc.moving_boxes + 2 * (size_t)idx); mx = get4(sc.moving_boxes + 2 * (size_t)idx + 1); }
-            c = f3(s) + time * f3(dc);  // MovingSphere::hit, src/hittable.rs:310
-            xf = sc.moving_xf + 2 * (size_t)idx;
-        }
-        if (ref_placed(ref)) {
-            ray_to_object(xf[0], xf[1], o, d);
-            a = dot3(d, d);
-        }
-        return sphere_root(c, s.w, o, d, a, tmin, tmax, t) && (!own_box || own_box_test_of_walk(mn, mx, o, d, inv, tmin, tmax));
-    } else {
-        if (COUNT) pr.quads++;
-        const float4* q4 = sc.quads + 4 * (size_t)idx;
-        const float4 nd = get4(q4);  // on its way while the placement is read and applied
-        if (ref_placed(ref)) ray_to_object(sc.quad_xf[2 * (size_t)idx], sc.quad_xf[2 * (size_t)idx + 1], o, d);
-        return quad_root(q4, nd, o, d, tmin, tmax, t, own_box ? sc.quad_boxes + 2 * (size_t)idx : nullptr, inv);
-    }
+    if (ref_kind(ref) != KIND_QUAD) return sphere_leaf_root<COUNT, OWN_BOX>(sc, ref, o, d, time, a, tmin, tmax, t, pr, inv);
+    return quad_leaf_root<COUNT, OWN_BOX>(sc, ref, o, d, tmin, tmax, t, pr, inv);
 }
 
 // AABB::hit / AABBx2::hit (src/math/aabb.rs:32-49,127-167) for one box and the interval [lo, hi]: min / max that drop a
@@ -1517,6 +1540,8 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
                   "the comparisons below spell out the layout of a reference");
     auto is_inner = [](uint32_t c) { return (int32_t)c >= 0; };
     auto is_prim = [](uint32_t c) { return (int32_t)c < (int32_t)0xE0000000u; };
+    auto is_sphere = [](uint32_t c) { return (int32_t)c < (int32_t)0xC0000000u; };  // still or moving
+    auto is_quad = [](uint32_t c) { return c - 0xC0000000u < 0x20000000u; };
     auto is_medium = [](uint32_t c) { return c - 0xE0000000u < 0x10000000u; };
     uint32_t mine = 0;  // queue slot this lane is working on (meaningful while cur != REF_NONE)
     uint32_t cur = REF_NONE, best = REF_NONE;
@@ -1533,9 +1558,18 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
     const unsigned long long t_start = wall_clock64();
     uint32_t node_turns = 0, overflow_turns = 0, my_visits = 0;
 #endif
+#ifdef RT_SECTION_TIMES  // development aid: shader-clock cycles every 64th wave spends in each part of the loop
+    unsigned long long t_sect[5] = {0, 0, 0, 0, 0}, t_mark = __builtin_readcyclecounter();
+    uint32_t n_sect[5] = {0, 0, 0, 0, 0};
+    const unsigned long long t_begin = t_mark;
+#define RT_SECTION_END(i, ran) { const unsigned long long t_now = __builtin_readcyclecounter(); t_sect[i] += t_now - t_mark; n_sect[i] += (ran) ? 1u : 0u; t_mark = t_now; }
+#else
+#define RT_SECTION_END(i, ran)
+#endif
     for (;;) {
         bool moved = false;
-        const int refill_min = eager ? 1 : tune.refill_min, inner_min = eager ? 1 : tune.inner_min, medium_min = eager ? 1 : tune.medium_min;
+        const int refill_min = eager ? 1 : tune.refill_min, inner_min = eager ? 1 : tune.inner_min, medium_min = eager ? 1 : tune.medium_min,
+                  quad_min = eager ? 1 : tune.quad_min;
         if (__ballot(cur == REF_DONE)) moved = true;
         if (cur == REF_DONE) {  // retire
 #ifdef RT_WAVE_TIMES
@@ -1559,7 +1593,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
 #if RT_LANE_STATS == 4
         if (COUNT) slots++;
 #endif
-        unsigned long long m_busy = __ballot(cur < 0xE0000000u);  // at an inner node, a sphere or a quad
+        unsigned long long m_busy = __ballot(cur < 0xC0000000u);  // at an inner node or a sphere: lanes whose work does not wait for others
         if (n_refill != 0 && ((int)__popcll(m_idle) >= refill_min || m_busy == 0)) {
             moved = true;
 #if RT_LANE_STATS == 3
@@ -1583,6 +1617,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             }
             next += n_refill;
         }
+        RT_SECTION_END(0, true)
         // inner nodes: as long as enough lanes are at one, or the lanes that are have nothing else to wait for.  (The decision
         // is the same for the whole wave and is computed as one scalar value, so that the loop is a scalar loop: left as a
         // loop with several exits, each costs every turn a handful of exec-mask instructions.)
@@ -1592,8 +1627,9 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             const int n_inner = (int)__popcll(__ballot(is_inner(cur)));
             int due = n_inner;
             if (n_inner != 0 && n_inner < inner_min) {
-                const int n_prim = (int)__popcll(__ballot(is_prim(cur))), n_med = (int)__popcll(__ballot(is_medium(cur)));
-                if (n_prim != 0 || n_med >= medium_min) due = 0;
+                const int n_sphere = (int)__popcll(__ballot(is_sphere(cur))), n_quad = (int)__popcll(__ballot(is_quad(cur))),
+                          n_med = (int)__popcll(__ballot(is_medium(cur)));
+                if (n_sphere != 0 || n_quad >= quad_min || n_med >= medium_min) due = 0;
                 else if (next < n && (int)__popcll(__ballot(cur >= REF_DONE)) >= refill_min) due = 0;  // lanes free or about to be
             }
             asm volatile("" : "+s"(due));  // (a value in a scalar register is the same in every lane by construction)
@@ -1620,20 +1656,46 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             node_turns++;
             if (__ballot(at_inner && st.sp > LDS_STACK)) overflow_turns++;
 #endif
+            RT_SECTION_END(1, true)
         }
-        // sphere and quad leaves
+        RT_SECTION_END(0, false)
+        // sphere leaves
         {
-            const bool at_prim = is_prim(cur);
+            const bool at_sphere = is_sphere(cur);
             const bool shallow = st.wave_is_shallow(0);  // (no lane's stack reaches into the global part: pops read LDS)
 #if RT_LANE_STATS == 2
-            if (COUNT && __ballot(at_prim)) slots++;
+            if (COUNT && __ballot(at_sphere)) slots++;
 #endif
-            if (__ballot(at_prim)) moved = true;
-            if (at_prim) {
+            if (__ballot(at_sphere)) moved = true;
+            if (at_sphere) {
                 float t;
-                if (leaf_root<COUNT, true>(sc, cur, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr, r.inv)) { tmax = t; best = cur; }
+                if (sphere_leaf_root<COUNT, true>(sc, cur, r.o, r.d, r.time, r.a, r.tmin, tmax, t, pr, r.inv)) { tmax = t; best = cur; }
                 cur = shallow ? st.pop_next_in_lds(tmax, 0xFFFFFFFFu, 0u) : pop_next(st, tmax);
             }
+            RT_SECTION_END(2, __ballot(at_sphere) != 0)
+        }
+        // quad leaves (and media, below): once enough lanes wait at one, or when the wave has nothing else it could do.  A quad's
+        // test is two memory round trips and as many instructions as a sphere's; run for every turn's two or three quads it
+        // would double the cost of the leaf part.
+        const bool can_refill = avail > n_refill || (__ballot(cur == REF_NONE) != 0 && next < n);
+        {
+            const bool at_quad = is_quad(cur);
+            const unsigned long long m_quad = __ballot(at_quad);
+            bool ran = false;
+            if (m_quad != 0) {
+                bool run = (int)__popcll(m_quad) >= quad_min;
+                if (!run) run = __ballot(cur < 0xC0000000u) == 0 && !can_refill;  // no lane at an inner node or a sphere, none to fill
+                if (run) {
+                    moved = ran = true;
+                    const bool shallow = st.wave_is_shallow(0);
+                    if (at_quad) {
+                        float t;
+                        if (quad_leaf_root<COUNT, true>(sc, cur, r.o, r.d, r.tmin, tmax, t, pr, r.inv)) { tmax = t; best = cur; }
+                        cur = shallow ? st.pop_next_in_lds(tmax, 0xFFFFFFFFu, 0u) : pop_next(st, tmax);
+                    }
+                }
+            }
+            RT_SECTION_END(3, ran)
         }
         // media: once enough lanes wait at one, or when the wave has nothing else it could do
         {
@@ -1643,7 +1705,6 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
                 bool run = (int)__popcll(m_med) >= medium_min;
                 if (!run) {
                     const unsigned long long m_other = __ballot(cur != REF_NONE) & ~m_med;  // includes finished rays: they free lanes
-                    const bool can_refill = avail > n_refill || (__ballot(cur == REF_NONE) != 0 && next < n);
                     run = m_other == 0 && !can_refill;
                 }
                 if (run) {
@@ -1659,8 +1720,14 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
                 }
             }
         }
+        RT_SECTION_END(4, __ballot(is_medium(cur)) != 0)
         eager = __ballot(!moved) != 0ull;
     }
+#ifdef RT_SECTION_TIMES
+    if (lane == 0 && (wave & 63u) == 0)
+        printf("sections %u %u total %llu fetch %llu %u node %llu %u sphere %llu %u quad %llu %u medium %llu %u\n", bounce, wave, __builtin_readcyclecounter() - t_begin,
+               t_sect[0], n_sect[0], t_sect[1], n_sect[1], t_sect[2], n_sect[2], t_sect[3], n_sect[3], t_sect[4], n_sect[4]);
+#endif
 #ifdef RT_WAVE_TIMES
     if (lane == 0 && ((wave & 255u) == 0 || node_turns > RT_WAVE_TIMES)) printf("wave %u %u start %llu end %llu turns %u overflow %u\n", bounce, wave, t_start, wall_clock64(), node_turns, overflow_turns);
 #endif
