@@ -101,6 +101,7 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
     uint32_t max_blocks = 2048;
     uint32_t extend_blocks = 1024;  // persistent grid of the extend kernel: what the chip holds at once
+    uint32_t extend_blocks_shared = 1024;  // the same for a render call whose batches run on two pipelines (see render)
     uint32_t extend_blocks_counting = 1024;  // the same for its counting build (more registers)
     uint32_t extend_blocks_generic = 1024, extend_blocks_counting_generic = 1024;  // the same for the variants that scenes with
                                                                                   // media of any boundary get (never more blocks)
@@ -531,6 +532,18 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
         c->extend_blocks_generic = (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::min(per_cu, per_cu_generic);
         c->extend_blocks_counting_generic =
             (uint32_t)std::max(1, prop.multiProcessorCount) * (uint32_t)std::min(std::min(per_cu, per_cu_generic), per_cu_counting_generic);
+#ifdef RT_DEV_KNOBS
+        if (const char* e = getenv("RT_AMD_EXTEND_BLOCKS")) c->extend_blocks = std::min(c->extend_blocks, (uint32_t)std::max(1, atoi(e)));  // whole grid
+#endif
+        // half a block per CU fewer when two pipelines share the chip
+        c->extend_blocks_shared = std::max(c->extend_blocks - (uint32_t)std::max(1, prop.multiProcessorCount) / 2u, (uint32_t)std::max(1, prop.multiProcessorCount));
+#ifdef RT_DEV_KNOBS
+        if (const char* e = getenv("RT_AMD_EXTEND_BLOCKS_SHARED")) c->extend_blocks_shared = (uint32_t)std::max(1, atoi(e));
+#endif
+        // the overflow area of the walk's stacks is sized for extend_blocks: no variant's grid may be larger
+        c->extend_blocks_counting = std::min(c->extend_blocks_counting, c->extend_blocks);
+        c->extend_blocks_generic = std::min(c->extend_blocks_generic, c->extend_blocks);
+        c->extend_blocks_counting_generic = std::min(c->extend_blocks_counting_generic, c->extend_blocks);
         int tail_per_cu = std::max(1, rt::tail_blocks_per_cu());
 #ifdef RT_DEV_KNOBS
         if (const char* e = getenv("RT_AMD_TAIL_BLOCKS_PER_CU")) tail_per_cu = std::max(1, atoi(e));
@@ -1312,6 +1325,11 @@ static int render_rows(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, u
     // persistent grid of the extend kernel; a preallocated overflow area bounds it for the trees that use that area
     uint32_t extend_grid = extend_grid_of(c, sc, c->counters_on);
     if (fixed && needs_overflow(sc)) extend_grid = std::min(extend_grid, NOALLOC_OVERFLOW_BLOCKS);
+    // With two pipelines the extend kernel of one batch runs beside the other batch's kernels.  A grid that fills every
+    // wave slot of the chip keeps those out until its waves drain; with half a block per CU fewer (6.5 instead of 7) the
+    // other batch's ray generation, first-leaves and shade passes - bound by memory, not by instruction issue - find room
+    // to run in its shadow (headline scene: 2680 Msamples/s with 7 blocks per CU, 2715 with 6.5, 2695 with 6, 2675 with 5.5).
+    if (n_pipes > 1) extend_grid = std::min(extend_grid, c->extend_blocks_shared);
     const bool overflow_needed = needs_overflow(sc);  // else the extend kernel runs the variant without the global part of its stack
     DCamera dcam = to_dcamera(cam);
     DCounters* counters = c->counters_on ? c->d_counters : nullptr;

@@ -106,6 +106,10 @@ ISSUE_KERNEL(k_cndmask_e64_vcc, "v_cndmask_b32_e64 %0, %0, %3, vcc")
 ISSUE_KERNEL(k_cmp_cndmask_vcc, "v_cmp_lt_u32 vcc, %2, %6\n\tv_cndmask_b32 %0, %0, %3, vcc")
 ISSUE_KERNEL(k_cmp_cndmask_sgpr, "v_cmp_lt_u32 s[20:21], %2, %6\n\tv_cndmask_b32_e64 %0, %0, %3, s[20:21]")
 ISSUE_KERNEL(k_cmp_cndmask_e64_vcc, "v_cmp_lt_u32 vcc, %2, %6\n\tv_cndmask_b32_e64 %0, %0, %3, vcc")
+ISSUE_KERNEL(k_cmp_2cndmask_vcc, "v_cmp_lt_u32 vcc, %2, %6\n\tv_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %2, %2, %6, vcc")
+ISSUE_KERNEL(k_cmp_2cndmask_sgpr, "v_cmp_lt_u32 s[20:21], %2, %6\n\tv_cndmask_b32_e64 %0, %0, %3, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %6, s[20:21]")
+ISSUE_KERNEL(k_sort_unit_vcc, "v_cmp_lt_u32 vcc, %2, %6\n\tv_min_u32 %2, %2, %6\n\tv_max_u32 %2, %2, %6\n\tv_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %0, %3, %0, vcc")
+ISSUE_KERNEL(k_sort_unit_sgpr, "v_cmp_lt_u32 s[20:21], %2, %6\n\tv_min_u32 %2, %2, %6\n\tv_max_u32 %2, %2, %6\n\tv_cndmask_b32_e64 %0, %0, %3, s[20:21]\n\tv_cndmask_b32_e64 %0, %3, %0, s[20:21]")
 ISSUE_KERNEL(k_div_scale, "v_div_scale_f32 %0, vcc, %0, %3, %0")
 ISSUE_KERNEL(k_div_fmas, "v_div_fmas_f32 %0, %0, %3, %4")
 ISSUE_KERNEL(k_div_fixup, "v_div_fixup_f32 %0, %0, %3, %4")
@@ -188,6 +192,7 @@ int main() {
     RUN(k_cndmask_sgpr, 1); RUN(k_cndmask_nodep, 1); RUN(k_cndmask_imm, 1); RUN(k_sub, 1); RUN(k_ashr, 1); RUN(k_or, 1); RUN(k_and_or, 1);
     RUN(k_min_f32, 1); RUN(k_fmac, 1); RUN(k_mad_u32_u24, 1); RUN(k_sub_u32, 1); RUN(k_lshrrev, 1);
     RUN(k_cndmask_e64_vcc, 1); RUN(k_cmp_cndmask_vcc, 2); RUN(k_cmp_cndmask_sgpr, 2); RUN(k_cmp_cndmask_e64_vcc, 2);
+    RUN(k_cmp_2cndmask_vcc, 3); RUN(k_cmp_2cndmask_sgpr, 3); RUN(k_sort_unit_vcc, 5); RUN(k_sort_unit_sgpr, 5);
     RUN(k_div_scale, 1); RUN(k_div_fmas, 1); RUN(k_div_fixup, 1); RUN(k_addc_vcc, 1); RUN(k_addc_sgpr, 1); RUN(k_add_co, 1); RUN(k_mad_u64_u32, 1);
     RUN(k_cmp_class, 1); RUN(k_readfirstlane, 1); RUN(k_log, 1); RUN(k_exp, 1); RUN(k_rsq, 1); RUN(k_mul_f64, 1); RUN(k_lshl_b64, 1);
     RUN(k_bfi, 1); RUN(k_alignbit, 1); RUN(k_med3, 1);
