@@ -51,7 +51,10 @@ struct EventPair {
     int phase;
 };
 
-constexpr int MAX_PIPES = 2;
+#ifndef RT_MAX_PIPES
+#define RT_MAX_PIPES 2
+#endif
+constexpr int MAX_PIPES = RT_MAX_PIPES;
 constexpr int MAX_DEVICES = 64;
 constexpr uint64_t BYTES_PER_PATH = 4 * sizeof(float4) + 2 * 3 * sizeof(float) + sizeof(uint2) + sizeof(uint32_t) + sizeof(float4);
 
@@ -1049,7 +1052,16 @@ int rt_scene_create(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
             }
             return upload(sc, flat, out);
         };
-        if ((e = boxes_of(sphere_box, &sc->d.sphere_boxes))) return bail(e);
+        // a sphere's box that is just centre -+ |radius| (none of its sides was padded) is computed by the kernels
+        bool plain = true;
+        for (uint32_t i = 0; i < desc->n_spheres && plain; ++i) {
+            const rt_sphere& s = desc->spheres[i];
+            if (s.transform != RT_NO_TRANSFORM) continue;  // (a placed sphere's box is not tested by the kernels)
+            const float ar = std::fabs(s.radius);
+            for (int a = 0; a < 3; ++a) plain = plain && sphere_box[i].mn[a] == s.centre[a] - ar && sphere_box[i].mx[a] == s.centre[a] + ar;
+        }
+        sc->d.plain_sphere_boxes = plain ? 1u : 0u;
+        if (!plain && (e = boxes_of(sphere_box, &sc->d.sphere_boxes))) return bail(e);
         if ((e = boxes_of(moving_box, &sc->d.moving_boxes))) return bail(e);
         if ((e = boxes_of(quad_box, &sc->d.quad_boxes))) return bail(e);
     }

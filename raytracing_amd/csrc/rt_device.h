@@ -159,6 +159,8 @@ struct DScene {
     uint32_t lds_perlin;       // 1: the scene has exactly one noise table and it fits the textured-shade kernel's LDS copy
     uint32_t textured;         // 1: some leaf's hits are of the textured shading class
     uint32_t generic_media;    // 1: some medium's boundary is not one sphere in world space (selects the kernels that hold the code for those)
+    uint32_t plain_sphere_boxes;  // 1: every sphere's own box is (centre - |radius|, centre + |radius|) as f32 arithmetic gives it (no box
+                                  // was padded): the kernels compute it from the sphere's record and sphere_boxes is NULL
     const uint32_t* global_refs;  // n_global leaf references tested ahead of the tree
 };
 

@@ -198,9 +198,11 @@ RT_D bool sphere_leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, f
     float4 mn = make_float4(0, 0, 0, 0), mx = mn;
     // (each kind reads its own arrays inside its branch: a pointer chosen by kind and used after the branches is a table
     // in scratch memory and a flat load to the compiler)
+    // (a still sphere's box is not read where the scene says that it follows from the sphere's record: two gathers fewer)
+    const bool computed_box = sc.plain_sphere_boxes != 0;
     if (kind == KIND_SPHERE) {
         s = get4(sc.spheres + idx);
-        if (own_box) { mn = get4(sc.sphere_boxes + 2 * (size_t)idx); mx = get4(sc.sphere_boxes + 2 * (size_t)idx + 1); }
+        if (own_box && !computed_box) { mn = get4(sc.sphere_boxes + 2 * (size_t)idx); mx = get4(sc.sphere_boxes + 2 * (size_t)idx + 1); }
         c = f3(s);
         xf = sc.sphere_xf + 2 * (size_t)idx;
     } else {
@@ -214,7 +216,14 @@ RT_D bool sphere_leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, f
         ray_to_object(xf[0], xf[1], o, d);
         a = dot3(d, d);
     }
-    return sphere_root(c, s.w, o, d, a, tmin, tmax, t) && (!own_box || own_box_test_of_walk(mn, mx, o, d, inv, tmin, tmax));
+    if (!sphere_root(c, s.w, o, d, a, tmin, tmax, t)) return false;
+    if (!own_box) return true;
+    if (computed_box && kind == KIND_SPHERE) {  // AABB::from_points(centre - rvec, centre + rvec), src/hittable.rs:160-163
+        const float ar = fabsf(s.w);
+        mn = make_float4(s.x - ar, s.y - ar, s.z - ar, 0.0f);
+        mx = make_float4(s.x + ar, s.y + ar, s.z + ar, 0.0f);
+    }
+    return own_box_test_of_walk(mn, mx, o, d, inv, tmin, tmax);
 }
 template <bool COUNT, bool OWN_BOX = false>
 RT_D bool quad_leaf_root(const DScene& sc, uint32_t ref, float3 o, float3 d, float tmin, float tmax, float& t, Probe& pr,
@@ -1539,7 +1548,6 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
     static_assert((REF_LEAF | (KIND_MEDIUM << 29)) == 0xE0000000u && REF_PLACED == 0x10000000u && KIND_MEDIUM == 3u && REF_DONE >= 0xF0000000u,
                   "the comparisons below spell out the layout of a reference");
     auto is_inner = [](uint32_t c) { return (int32_t)c >= 0; };
-    auto is_prim = [](uint32_t c) { return (int32_t)c < (int32_t)0xE0000000u; };
     auto is_sphere = [](uint32_t c) { return (int32_t)c < (int32_t)0xC0000000u; };  // still or moving
     auto is_quad = [](uint32_t c) { return c - 0xC0000000u < 0x20000000u; };
     auto is_medium = [](uint32_t c) { return c - 0xE0000000u < 0x10000000u; };
