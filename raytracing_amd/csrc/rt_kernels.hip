@@ -690,12 +690,19 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
     if (COUNT) pr.nodes++;
     const uint32_t base = cur * 64u;
     uint4v g0, g1, g2, g3;
+#ifdef RT_EXTRA_NODE_LOADS
+    uint32_t extra_word = 0;
+#endif
     if (LDS_TOP && cur < src.n_top) {
         lds_bytes* n = (lds_bytes*)src.top;
         g0 = *(const lds_uint4v*)(n + base); g1 = *(const lds_uint4v*)(n + (base + 16u));
         g2 = *(const lds_uint4v*)(n + (base + 32u)); g3 = *(const lds_uint4v*)(n + (base + 48u));
     } else {
         const char* n = (const char*)src.nodes;
+#ifdef RT_EXTRA_NODE_LOADS  // timing experiments (development builds): more bytes through the L1 from the node's own cache line
+#pragma unroll
+        for (int x = 0; x < RT_EXTRA_NODE_LOADS; ++x) asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(extra_word) : "v"(n + base), "n"(4 * x) : "memory");
+#endif
         g0 = *(const uint4v*)(n + base); g1 = *(const uint4v*)(n + (base + 16u));
         g2 = *(const uint4v*)(n + (base + 32u)); g3 = *(const uint4v*)(n + (base + 48u));
     }
@@ -762,6 +769,9 @@ RT_D uint32_t node_step(const NodeSource& src, const TravRay& r, uint32_t cur, f
     }
 #endif
     const uint32_t refs[4] = {g3.x, g3.y, g3.z, g3.w};
+#ifdef RT_EXTRA_NODE_LOADS
+    asm volatile("" :: "v"(extra_word), "v"(g3.x));  // (loads return in order: the extra ones have arrived once the node's last group has)
+#endif
     uint32_t key[4], ref[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1479,9 +1489,12 @@ static constexpr int SMALL_TREE_NODES = 96;  // 6 KiB of nodes
 #ifndef RT_EXTEND_STACK
 #define RT_EXTEND_STACK 11  // stack levels per lane kept in LDS (large trees): 22 KiB per block, seven blocks per CU
 #endif
+#ifndef RT_EXTEND_TOP_NODES
+#define RT_EXTEND_TOP_NODES 0
+#endif
 template <bool SMALL_TREE> struct ExtendLds {
     static constexpr int STACK_LEVELS = SMALL_TREE ? 8 : RT_EXTEND_STACK;
-    static constexpr int TOP_NODES = SMALL_TREE ? SMALL_TREE_NODES : 0;
+    static constexpr int TOP_NODES = SMALL_TREE ? SMALL_TREE_NODES : RT_EXTEND_TOP_NODES;
 };
 static constexpr int MIN_LDS_STACK = 8;
 static constexpr int OVERFLOW_STACK = STACK_SIZE - MIN_LDS_STACK;
@@ -1650,7 +1663,7 @@ __global__ __launch_bounds__(EXTEND_BLOCK) __attribute__((amdgpu_waves_per_eu(GE
             if (COUNT) slots++;
 #endif
             if (at_inner) {
-                cur = node_step<COUNT, SMALL_TREE>(src, r, cur, tmax, st, pr);
+                cur = node_step<COUNT, (LDS_TOP_NODES > 0)>(src, r, cur, tmax, st, pr);
                 if (COUNT) pr.max_sp = max(pr.max_sp, (uint32_t)st.sp);
 #if RT_LANE_STATS == 7
                 if (COUNT && st.sp > LDS_STACK) slots++;  // node steps that leave the lane's stack in the global part
