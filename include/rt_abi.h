@@ -287,7 +287,7 @@ int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream);
 /* Paths kept in flight per batch (queue capacity); 0 restores the default. */
 int rt_ctx_set_batch_paths(rt_ctx* ctx, uint64_t max_paths);
 /* Batches of one render call that are in flight at a time (1 or 2, default 2;
- * only calls with >= 2 samples and >= 4 Mi paths are split).  With 2 the
+ * only calls with >= 2 samples and >= 16 Mi paths are split).  With 2 the
  * batches run on two internal streams that start after the work already on the
  * context's stream and that the context's stream waits for; the accumulation
  * buffer takes the batches in sample order either way, so results are

@@ -103,6 +103,7 @@ struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     uint32_t max_blocks = 2048;
+    uint32_t shade_blocks = 2048;   // grid limit of the shade kernel
     uint32_t extend_blocks = 1024;  // persistent grid of the extend kernel: what the chip holds at once
     uint32_t extend_blocks_shared = 1024;  // the same for a render call whose batches run on two pipelines (see render)
     uint32_t extend_blocks_counting = 1024;  // the same for its counting build (more registers)
@@ -520,6 +521,10 @@ int rt_ctx_create(int device_id, rt_ctx** out) {
     rt_ctx* c = new rt_ctx();
     c->device = device_id;
     c->max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
+    c->shade_blocks = c->max_blocks;
+#ifdef RT_DEV_KNOBS
+    if (const char* e = getenv("RT_AMD_SHADE_BLOCKS")) c->shade_blocks = (uint32_t)std::max(1, atoi(e));
+#endif
     {
         int per_cu = rt::extend_blocks_per_cu(false, false), per_cu_counting = rt::extend_blocks_per_cu(true, false);
         int per_cu_generic = rt::extend_blocks_per_cu(false, true), per_cu_counting_generic = rt::extend_blocks_per_cu(true, true);
@@ -1301,8 +1306,11 @@ static int render_rows(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, u
     const uint64_t pix0 = (uint64_t)first_row * cam->width;     // the rows are one contiguous range of pixels
     const uint64_t npix = (uint64_t)cam->width * n_rows;
     const uint64_t all_paths = npix * (uint64_t)n_samples;
-    // one pipeline for small jobs (and for single-sample calls, which are not split)
-    const int n_pipes = (!fixed && c->n_pipes > 1 && n_samples >= 2 && all_paths >= (1ull << 22)) ? c->n_pipes : 1;
+    // one pipeline for small jobs (and for single-sample calls, which are not split): halves of a call below 16 M paths are batches
+    // so small that their own per-bounce latencies cost more than the overlap gives (Book-1 scene 400x225, depth 50, 100 samples per
+    // call, 9 M paths: 2.96 ms on one pipeline, 3.32 on two; 18 M paths: 6.2 against 5.3; the Cornell box still gains 4 - 5 % from two
+    // at 8 - 13 M paths, the Book-2 scene nothing)
+    const int n_pipes = (!fixed && c->n_pipes > 1 && n_samples >= 2 && all_paths >= (1ull << 24)) ? c->n_pipes : 1;
     Pipe* pipes[MAX_PIPES];
     for (int i = 0; i < MAX_PIPES; ++i) pipes[i] = fixed ? fixed : &c->pipes[i];
     const bool timing = c->phase_timing && !fixed;
@@ -1386,7 +1394,7 @@ static int render_rows(rt_scene* sc, const rt_camera_desc* cam, uint64_t seed, u
                                   q.ray_d[cur], q.hits, overflow_needed ? q.stack_overflow : nullptr, tune, counters);
                     if ((e = phase_end(st, ep))) return e;
                     if ((e = phase_begin(c, timing, st, 2, &ep))) return e;
-                    launch_shade(st, c->max_blocks, total, sc->d, dcam, b, seed, bounce, q.counts, q.counts + n_queue_counts + bounce, q.tex_list,
+                    launch_shade(st, c->shade_blocks, total, sc->d, dcam, b, seed, bounce, q.counts, q.counts + n_queue_counts + bounce, q.tex_list,
                                  q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.hits, q.ray_o[cur ^ 1], q.ray_d[cur ^ 1], q.thr[cur ^ 1], q.radiance,
                                  sc->has_textures);
                     if ((e = phase_end(st, ep))) return e;

@@ -787,9 +787,9 @@ def test_contexts_of_several_host_threads_render_side_by_side():
 
 
 def test_two_pipelines_give_the_same_image_as_one():
-    """A render large enough to be split over the two internal streams (>= 4 Mi paths) equals the
+    """A render large enough to be split over the two internal streams (>= 16 Mi paths) equals the
     one-stream render bit for bit, also when the sample count does not divide evenly."""
-    w, h, spp = 1024, 832, 5
+    w, h, spp = 1024, 832, 21
     one = rt.Scene.builtin(6, w, h)
     one.set_pipelines(1)
     one.render_samples(spp)
@@ -798,7 +798,7 @@ def test_two_pipelines_give_the_same_image_as_one():
     two.set_pipelines(2)
     two.render_samples(spp)
     assert np.array_equal(ref, two.accumulator())
-    two.set_batch_paths(w * h)     # five batches of one sample, alternating pipelines
+    two.set_batch_paths(w * h)     # 21 batches of one sample, alternating pipelines
     two.render_samples(spp)
     one.render_samples(spp)
     assert np.array_equal(one.accumulator(), two.accumulator())
